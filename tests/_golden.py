@@ -1,0 +1,83 @@
+"""Loader for the committed golden fixtures (made by oracle/gen_golden.py from the reference)."""
+from __future__ import annotations
+
+import glob
+import os
+
+import numpy as np
+import scipy.sparse as sps
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALL_KEYS = (
+    "flux",
+    "bound_flux",
+    "bound_pressure_cell",
+    "bound_pressure_face",
+    "vector_source",
+    "bound_pressure_vector_source",
+)
+
+
+def case_names():
+    names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
+    return [n for n in names if n != "scalar_known_answers"]
+
+
+class Case:
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.grid["name"] = str(self.grid["name"])
+        self.bc = {k[3:]: z[k] for k in z.files if k.startswith("bc_") and k != "bc_values"}
+        self.perm = z["perm"]
+        self.bc_values = z["bc_values"]
+        self.source = z["source"]
+        eta = float(z["eta"])
+        self.eta = None if np.isnan(eta) else eta
+        self.vector_source_values = z["vector_source_values"] if "vector_source_values" in z.files else None
+        self.ref = {}
+        for k in ALL_KEYS + ("A",):
+            if f"ref_{k}_indptr" in z.files:
+                shape = tuple(int(v) for v in z[f"ref_{k}_shape"])
+                self.ref[k] = sps.csr_matrix(
+                    (z[f"ref_{k}_data"], z[f"ref_{k}_indices"], z[f"ref_{k}_indptr"]), shape=shape
+                )
+        self.ref_rhs = z["ref_rhs"]
+        self.ref_x = z["ref_x"]
+        self.known_u = z["known_u"] if "known_u" in z.files else None
+        self.known_flux = z["known_flux"] if "known_flux" in z.files else None
+
+
+def rel_max_err(ours, ref) -> float:
+    """max|ours - ref| / max|ref|  (SURVEY 8(d) parity metric (2))."""
+    ours, ref = sps.csr_matrix(ours), sps.csr_matrix(ref)
+    scale = abs(ref).max() if ref.nnz else 1.0
+    diff = abs(ours - ref).max() if (ours.nnz + ref.nnz) else 0.0
+    return float(diff / (scale if scale > 0 else 1.0))
+
+
+def stored_pattern(m) -> set:
+    c = sps.coo_matrix(m)
+    return set(zip(c.row.tolist(), c.col.tolist()))
+
+
+def check_pattern(ours, ref, tol=1e-12):
+    """Pattern rule of SURVEY 8(d)(1): ref's stored pattern is a subset of ours and
+    anything we store outside it is below tol * max|row of ref| (entries below the
+    absolute roundoff floor 1e-15 * max|ref| are ignored: some reference rows are pure noise).  Returns (subset_ok, max_outside_ratio, equal)."""
+    ours, ref = sps.csr_matrix(ours), sps.csr_matrix(ref)
+    po, pr = stored_pattern(ours), stored_pattern(ref)
+    subset = pr <= po
+    rowmax = np.maximum(abs(ref).max(axis=1).toarray().ravel(), 0)
+    gmax = abs(ref).max() if ref.nnz else 1.0
+    worst = 0.0
+    oc = ours.tocoo()
+    for r, c, v in zip(oc.row, oc.col, oc.data):
+        if (r, c) not in pr:
+            if abs(v) <= 1e-15 * gmax:  # absolute roundoff floor (rows that are all noise)
+                continue
+            denom = rowmax[r] if rowmax[r] > 0 else gmax
+            worst = max(worst, abs(v) / denom)
+    return subset, worst, po == pr
