@@ -1,0 +1,157 @@
+/* porefv.h — C ABI of libporefv_hip.so: MI355X-native MPFA-O assembly + sparse solve.
+ *
+ * This is the drop-in boundary for PorePy's finite-volume hot path.  PorePy is pure
+ * Python, so the binding a maintainer adds is a ctypes stub; each
+ * entry point names the reference code it stands in for (paths relative to
+ * /root/reference/src/porepy).  Plain pointers and sizes only; no torch / numpy types.
+ *
+ * Conventions
+ *   - every function returns a pfv_status (0 = ok); pfv_last_error() gives the text
+ *   - all floating point is FP64, all indices int32 (CSR outputs as scipy stores them)
+ *   - geometry arrays are SoA with 3 rows, row-major: a[3][N]   (Grid.nodes etc.)
+ *   - "host" pointers are read/written synchronously; the handle owns all device memory
+ *   - one handle = one HIP device + one stream; calls on a handle are blocking and
+ *     must not be issued concurrently (the reference is single-threaded too)
+ */
+#ifndef POREFV_H
+#define POREFV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pfv_ctx pfv_ctx;
+
+typedef enum {
+  PFV_OK = 0,
+  PFV_ERR_SINGULAR = 1,      /* ValueError("Error in inversion of local linear systems"),
+                                numerics/linalg/matrix_operations.py:1487-1490 */
+  PFV_ERR_CELL_SHAPE = 2,    /* AssertionError: != nd faces of a cell meet in a node,
+                                numerics/fv/_fvutils.py:735-736 */
+  PFV_ERR_HIP = 3,           /* HIP runtime error; text in pfv_last_error */
+  PFV_ERR_ARGUMENT = 4,      /* bad argument / call order */
+  PFV_ERR_UNSUPPORTED = 5,   /* size or feature outside what the kernels cover */
+  PFV_ERR_NOT_CONVERGED = 6  /* Krylov solve hit maxit (solution still returned) */
+} pfv_status;
+
+/* matrix selectors; 0..5 are the six keys FVElliptic stores
+ * (numerics/fv/fv_elliptic.py:30-53), 6 is A = div @ flux (fv_elliptic.py:90-96) */
+enum {
+  PFV_MAT_FLUX = 0,
+  PFV_MAT_BOUND_FLUX = 1,
+  PFV_MAT_BOUND_PRESSURE_CELL = 2,
+  PFV_MAT_BOUND_PRESSURE_FACE = 3,
+  PFV_MAT_VECTOR_SOURCE = 4,
+  PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE = 5,
+  PFV_MAT_SYSTEM = 6,
+  PFV_NUM_MATS = 7
+};
+
+/* boundary-condition flag bits per face (params/bc.py:68-190: is_dir/is_neu/is_rob/
+ * is_internal of BoundaryCondition) */
+enum { PFV_BC_DIR = 1, PFV_BC_NEU = 2, PFV_BC_ROB = 4, PFV_BC_INTERNAL = 8 };
+
+/* Krylov methods for pfv_solve (the reference only has direct solvers,
+ * models/solution_strategy.py:830-884; results are judged against its solution) */
+enum { PFV_SOLVE_CG = 0, PFV_SOLVE_BICGSTAB = 1, PFV_SOLVE_GMRES = 2 };
+
+/* flags for pfv_mpfa_discretize */
+enum {
+  PFV_DISCR_REBUILD_TOPOLOGY = 1, /* redo sub-cell topology + CSR symbolic phase even if
+                                     cached (what every Mpfa.discretize call does) */
+  PFV_DISCR_SKIP_VECTOR_SOURCE = 2 /* do not fill matrices 4 and 5 */
+};
+
+typedef struct {
+  int32_t iterations;
+  int32_t converged;
+  double rel_residual; /* ||b - A x|| / ||b|| as tracked by the recurrence */
+  double solve_ms;     /* device time of the solve (HIP events) */
+} pfv_solve_info;
+
+/* phase timings of the last calls, milliseconds, measured with HIP events on the
+ * handle's stream (the reference logs wall-clock per phase:
+ * models/solution_strategy.py:435-442,807-828,846-884) */
+typedef struct {
+  double topology_ms;     /* SubcellTopology equivalent          (_fvutils.py:51-172)   */
+  double symbolic_ms;     /* CSR patterns of the 6 matrices + A                            */
+  double node_ms;         /* interaction-region kernel            (mpfa.py:997-1045)     */
+  double face_ms;         /* stencil scatter into CSR             (mpfa.py:1088-1147)    */
+  double assemble_ms;     /* div @ flux, rhs                      (fv_elliptic.py:67-112) */
+  double solve_ms;
+  double bytes_written_outputs; /* 8*nnz (+4*nnz per distinct pattern) of what was filled */
+  int64_t num_nodes, num_sub_half_faces, sum_block_sq, max_block;
+} pfv_stats;
+
+pfv_status pfv_create(int device, pfv_ctx** out);
+void pfv_destroy(pfv_ctx* h);
+const char* pfv_last_error(pfv_ctx* h);
+/* 1 if the library was built as the gfx950 HIP product, 0 for the host emulation build
+ * that tests use to exercise the kernel logic without a GPU */
+int pfv_is_device_build(void);
+
+/* Grid arrays, the fields of pp.Grid the path reads (grids/grid.py:78-272):
+ * cell_faces (CSC, Nf x Nc, data +-1, sorted indices), face_nodes (CSC, Nn x Nf),
+ * nodes, face_normals, face_centers, cell_centers (3 x N), face_areas. */
+pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn,
+                        const double* nodes, const int32_t* cf_indptr,
+                        const int32_t* cf_indices, const int8_t* cf_sign,
+                        const int32_t* fn_indptr, const int32_t* fn_indices,
+                        const double* face_normals, const double* face_centers,
+                        const double* cell_centers, const double* face_areas);
+
+/* Discretization parameters (numerics/fv/mpfa.py:119-167): permeability as
+ * SecondOrderTensor.values, shape (3,3,Nc) C-order; bc flags; Robin weight per face
+ * (may be NULL = 1); eta scalar, or per-subface array (length = nnz(face_nodes), in
+ * face_nodes CSC order) when eta_subface != NULL. */
+pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t* bc_flags,
+                               const double* robin_weight, double eta,
+                               const double* eta_subface);
+
+/* Mpfa._flux_discretization (numerics/fv/mpfa.py:592-1156) on the device. */
+pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags);
+
+/* shape and nnz of a produced matrix */
+pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols,
+                           int64_t* nnz);
+/* copy a matrix to caller-allocated CSR arrays (indptr nrows+1, indices nnz, data nnz);
+ * any pointer may be NULL to skip that array */
+pfv_status pfv_get_matrix(pfv_ctx* h, int which, int32_t* indptr, int32_t* indices,
+                          double* data);
+
+/* FVElliptic.assemble_matrix_rhs (numerics/fv/fv_elliptic.py:67-112):
+ * A = div @ flux, b = -div @ bound_flux @ bc_values - div @ vector_source @ g + source.
+ * vector_source (Nc*nd) and source (Nc) may be NULL.  Results stay on the device. */
+pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* vector_source,
+                             const double* source);
+pfv_status pfv_get_rhs(pfv_ctx* h, double* b);
+
+/* y = M x for a produced matrix; host vectors (testing / flux post-processing) */
+pfv_status pfv_spmv(pfv_ctx* h, int which, const double* x, double* y);
+
+/* Jacobi-preconditioned Krylov solve of A x = b on the device (stand-in for
+ * SolutionStrategy.solve_linear_system, models/solution_strategy.py:830-884).
+ * x0 may be NULL (zero start); x receives Nc values. */
+pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart,
+                     const double* x0, double* x, pfv_solve_info* info);
+
+/* Device-pointer variants for multi-GPU drivers that keep vectors in HBM
+ * (torch tensors): y = A x on the handle's stream; d_x has num_cols entries. */
+pfv_status pfv_spmv_device(pfv_ctx* h, int which, const double* d_x, double* d_y);
+pfv_status pfv_get_device_rhs(pfv_ctx* h, double** d_b, double** d_diag);
+pfv_status pfv_sync(pfv_ctx* h);
+
+pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out);
+
+/* Measurement hook for bench.py: average duration (ms, HIP events on the handle's stream)
+ * of `reps` back-to-back launches of one kernel on the data currently in the handle.
+ * kernel: 0 = CSR SpMV with A, 1 = interaction-region (node) kernel, 2 = face kernel. */
+enum { PFV_KERNEL_SPMV_A = 0, PFV_KERNEL_NODE = 1, PFV_KERNEL_FACE = 2 };
+pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POREFV_H */

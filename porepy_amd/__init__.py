@@ -1,0 +1,21 @@
+"""porepy_amd — MI355X-native MPFA-O assembly + sparse solve behind PorePy's
+``Discretization.discretize()`` / ``assemble_matrix_rhs()`` operator API.
+
+Only the hot path lives here: grids, parameters and the operator class are the
+host-side mirror of the reference interface; the arithmetic is in ``csrc/`` (HIP, gfx950),
+reached through the C ABI of ``include/porefv.h``.
+"""
+from . import _lib
+from ._lib import Context, PorefvError
+from .grid import (CartGrid, Grid, StructuredTetrahedralGrid, StructuredTriangleGrid, grid_to_raw,
+                   perturb_interior_nodes)
+from .mpfa import Mpfa, as_porepy_discretization, determine_eta
+from .params import (DISCRETIZATION_MATRICES, PARAMETERS, BoundaryCondition, SecondOrderTensor,
+                     bc_flags, bc_to_raw, initialize_data)
+
+__all__ = [
+    "Context", "PorefvError", "Grid", "CartGrid", "StructuredTriangleGrid",
+    "StructuredTetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "Mpfa",
+    "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition",
+    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib",
+]

@@ -1,0 +1,275 @@
+"""ctypes binding of the C ABI in include/porefv.h.
+
+The product library is ``porepy_amd/csrc/libporefv_hip.so`` (hipcc, gfx950).  There is no
+CPU fallback: if the library is missing, was not built for the device, or no GPU is
+visible, creating a context raises.  ``load_library(path)`` exists so that tests can bind
+the host-emulation build of the same sources explicitly; nothing in this package does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "libporefv_hip.so")
+
+MAT_FLUX, MAT_BOUND_FLUX, MAT_BOUND_PRESSURE_CELL, MAT_BOUND_PRESSURE_FACE = 0, 1, 2, 3
+MAT_VECTOR_SOURCE, MAT_BOUND_PRESSURE_VECTOR_SOURCE, MAT_SYSTEM = 4, 5, 6
+BC_DIR, BC_NEU, BC_ROB, BC_INTERNAL = 1, 2, 4, 8
+SOLVE_CG, SOLVE_BICGSTAB, SOLVE_GMRES = 0, 1, 2
+DISCR_REBUILD_TOPOLOGY, DISCR_SKIP_VECTOR_SOURCE = 1, 2
+
+STATUS_NAMES = {
+    0: "ok", 1: "singular local system", 2: "unsupported cell shape", 3: "HIP error",
+    4: "bad argument", 5: "unsupported size/feature", 6: "not converged",
+}
+
+EXPORTS = [
+    "pfv_create", "pfv_destroy", "pfv_last_error", "pfv_is_device_build", "pfv_set_grid",
+    "pfv_mpfa_set_params", "pfv_mpfa_discretize", "pfv_matrix_info", "pfv_get_matrix",
+    "pfv_mpfa_assemble", "pfv_get_rhs", "pfv_spmv", "pfv_solve", "pfv_spmv_device",
+    "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel",
+]
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32),
+                ("rel_residual", C.c_double), ("solve_ms", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("topology_ms", C.c_double), ("symbolic_ms", C.c_double), ("node_ms", C.c_double),
+                ("face_ms", C.c_double), ("assemble_ms", C.c_double), ("solve_ms", C.c_double),
+                ("bytes_written_outputs", C.c_double), ("num_nodes", C.c_int64),
+                ("num_sub_half_faces", C.c_int64), ("sum_block_sq", C.c_int64),
+                ("max_block", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class PorefvError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"porefv status {status} ({STATUS_NAMES.get(status, '?')}): {message}")
+        self.status = status
+        self.message = message
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_int8)
+_up = C.POINTER(C.c_uint8)
+_lp = C.POINTER(C.c_int64)
+_h = C.c_void_p
+
+
+def _bind(lib: C.CDLL) -> C.CDLL:
+    lib.pfv_create.argtypes = [C.c_int, C.POINTER(_h)]
+    lib.pfv_create.restype = C.c_int
+    lib.pfv_destroy.argtypes = [_h]
+    lib.pfv_destroy.restype = None
+    lib.pfv_last_error.argtypes = [_h]
+    lib.pfv_last_error.restype = C.c_char_p
+    lib.pfv_is_device_build.argtypes = []
+    lib.pfv_is_device_build.restype = C.c_int
+    lib.pfv_set_grid.argtypes = [_h, C.c_int, C.c_int64, C.c_int64, C.c_int64, _dp, _ip, _ip, _bp,
+                                 _ip, _ip, _dp, _dp, _dp, _dp]
+    lib.pfv_set_grid.restype = C.c_int
+    lib.pfv_mpfa_set_params.argtypes = [_h, _dp, _up, _dp, C.c_double, _dp]
+    lib.pfv_mpfa_set_params.restype = C.c_int
+    lib.pfv_mpfa_discretize.argtypes = [_h, C.c_uint32]
+    lib.pfv_mpfa_discretize.restype = C.c_int
+    lib.pfv_matrix_info.argtypes = [_h, C.c_int, _lp, _lp, _lp]
+    lib.pfv_matrix_info.restype = C.c_int
+    lib.pfv_get_matrix.argtypes = [_h, C.c_int, _ip, _ip, _dp]
+    lib.pfv_get_matrix.restype = C.c_int
+    lib.pfv_mpfa_assemble.argtypes = [_h, _dp, _dp, _dp]
+    lib.pfv_mpfa_assemble.restype = C.c_int
+    lib.pfv_get_rhs.argtypes = [_h, _dp]
+    lib.pfv_get_rhs.restype = C.c_int
+    lib.pfv_spmv.argtypes = [_h, C.c_int, _dp, _dp]
+    lib.pfv_spmv.restype = C.c_int
+    lib.pfv_solve.argtypes = [_h, C.c_int, C.c_double, C.c_int, C.c_int, _dp, _dp, C.POINTER(SolveInfo)]
+    lib.pfv_solve.restype = C.c_int
+    lib.pfv_spmv_device.argtypes = [_h, C.c_int, C.c_void_p, C.c_void_p]
+    lib.pfv_spmv_device.restype = C.c_int
+    lib.pfv_get_device_rhs.argtypes = [_h, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.pfv_get_device_rhs.restype = C.c_int
+    lib.pfv_sync.argtypes = [_h]
+    lib.pfv_sync.restype = C.c_int
+    lib.pfv_get_stats.argtypes = [_h, C.POINTER(Stats)]
+    lib.pfv_get_stats.restype = C.c_int
+    lib.pfv_time_kernel.argtypes = [_h, C.c_int, C.c_int, _dp]
+    lib.pfv_time_kernel.restype = C.c_int
+    return lib
+
+
+def load_library(path: str) -> C.CDLL:
+    """Bind a build of the porefv sources at an explicit path (tests use this for the
+    host-emulation build; the product only ever binds DEFAULT_LIBRARY)."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    return _bind(C.CDLL(path))
+
+
+_product = None
+
+
+def product_library() -> C.CDLL:
+    """The gfx950 HIP library.  Fails loudly when it is missing or is not a device build."""
+    global _product
+    if _product is None:
+        if not os.path.exists(DEFAULT_LIBRARY):
+            raise RuntimeError(
+                f"{DEFAULT_LIBRARY} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        lib = _bind(C.CDLL(DEFAULT_LIBRARY))
+        if not lib.pfv_is_device_build():
+            raise RuntimeError(f"{DEFAULT_LIBRARY} is not a HIP device build")
+        _product = lib
+    return _product
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class Context:
+    """One device handle (one GPU, one HIP stream): grid + parameters + results in HBM."""
+
+    def __init__(self, device: int = 0, library: C.CDLL | None = None):
+        self.lib = library if library is not None else product_library()
+        self._h = _h()
+        st = self.lib.pfv_create(int(device), C.byref(self._h))
+        if st != 0:
+            self._h = _h()
+            raise PorefvError(st, "pfv_create failed: no usable MI355X / HIP device "
+                                  "(the product path has no CPU fallback)")
+        self.nd = self.nc = self.nf = self.nn = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.pfv_destroy(self._h)
+            self._h = _h()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int):
+        if st != 0:
+            raise PorefvError(st, self.lib.pfv_last_error(self._h).decode(errors="replace"))
+
+    # ---- inputs -------------------------------------------------------------------
+    def set_grid(self, raw: dict):
+        nd = int(raw["dim"])
+        nodes = _f64(raw["nodes"]); fn_ = _f64(raw["face_normals"]); fc = _f64(raw["face_centers"])
+        cc = _f64(raw["cell_centers"]); fa = _f64(raw["face_areas"])
+        cfp = np.ascontiguousarray(raw["cf_indptr"], dtype=np.int32)
+        cfi = np.ascontiguousarray(raw["cf_indices"], dtype=np.int32)
+        cfs = np.ascontiguousarray(raw["cf_sign"], dtype=np.int8)
+        fnp = np.ascontiguousarray(raw["fn_indptr"], dtype=np.int32)
+        fni = np.ascontiguousarray(raw["fn_indices"], dtype=np.int32)
+        nc, nf, nn = cc.shape[1], fc.shape[1], nodes.shape[1]
+        if cfp.size != nc + 1 or fnp.size != nf + 1 or nodes.shape[0] != 3:
+            raise ValueError("inconsistent grid arrays")
+        self._check(self.lib.pfv_set_grid(
+            self._h, nd, nc, nf, nn, _ptr(nodes, _dp), _ptr(cfp, _ip), _ptr(cfi, _ip), _ptr(cfs, _bp),
+            _ptr(fnp, _ip), _ptr(fni, _ip), _ptr(fn_, _dp), _ptr(fc, _dp), _ptr(cc, _dp), _ptr(fa, _dp)))
+        self.nd, self.nc, self.nf, self.nn = nd, nc, nf, nn
+        self.nsf = int(fnp[-1])
+
+    def set_params(self, perm, bc_flags, robin_weight=None, eta=0.0, eta_subface=None):
+        perm = _f64(perm)
+        if perm.shape != (3, 3, self.nc):
+            raise ValueError(f"permeability must have shape (3, 3, {self.nc})")
+        flags = np.ascontiguousarray(bc_flags, dtype=np.uint8)
+        if flags.shape != (self.nf,):
+            raise ValueError("bc flags must have one entry per face")
+        rw = None if robin_weight is None else _f64(robin_weight)
+        es = None if eta_subface is None else _f64(eta_subface)
+        if es is not None and es.shape != (self.nsf,):
+            raise ValueError("size of eta must either be 1 or number of subfaces")
+        self._check(self.lib.pfv_mpfa_set_params(self._h, _ptr(perm, _dp), _ptr(flags, _up),
+                                                 _ptr(rw, _dp), float(eta), _ptr(es, _dp)))
+
+    # ---- hot path -----------------------------------------------------------------
+    def discretize(self, rebuild_topology=False, skip_vector_source=False):
+        flags = (DISCR_REBUILD_TOPOLOGY if rebuild_topology else 0) | \
+                (DISCR_SKIP_VECTOR_SOURCE if skip_vector_source else 0)
+        self._check(self.lib.pfv_mpfa_discretize(self._h, flags))
+
+    def matrix_info(self, which: int):
+        r, c, z = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.pfv_matrix_info(self._h, which, C.byref(r), C.byref(c), C.byref(z)))
+        return r.value, c.value, z.value
+
+    def matrix(self, which: int):
+        """Copy a result matrix to the host as scipy csr (int32 sorted indices, FP64)."""
+        import scipy.sparse as sps
+
+        nrows, ncols, nnz = self.matrix_info(which)
+        indptr = np.empty(nrows + 1, dtype=np.int32)
+        indices = np.empty(nnz, dtype=np.int32)
+        data = np.empty(nnz, dtype=np.float64)
+        self._check(self.lib.pfv_get_matrix(self._h, which, _ptr(indptr, _ip), _ptr(indices, _ip),
+                                            _ptr(data, _dp)))
+        return sps.csr_matrix((data, indices, indptr), shape=(nrows, ncols))
+
+    def assemble(self, bc_values, vector_source=None, source=None):
+        bcv = _f64(bc_values)
+        if bcv.shape != (self.nf,):
+            raise ValueError("bc_values must have one entry per face")
+        vs = None if vector_source is None else _f64(vector_source)
+        src = None if source is None else _f64(source)
+        self._check(self.lib.pfv_mpfa_assemble(self._h, _ptr(bcv, _dp), _ptr(vs, _dp), _ptr(src, _dp)))
+
+    def rhs(self):
+        b = np.empty(self.nc, dtype=np.float64)
+        self._check(self.lib.pfv_get_rhs(self._h, _ptr(b, _dp)))
+        return b
+
+    def spmv(self, which: int, x):
+        nrows, ncols, _ = self.matrix_info(which)
+        x = _f64(x)
+        if x.shape != (ncols,):
+            raise ValueError("dimension mismatch")
+        y = np.empty(nrows, dtype=np.float64)
+        self._check(self.lib.pfv_spmv(self._h, which, _ptr(x, _dp), _ptr(y, _dp)))
+        return y
+
+    def solve(self, method="bicgstab", rtol=1e-12, maxit=10000, x0=None, raise_on_fail=True):
+        code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB}[method]
+        x = np.empty(self.nc, dtype=np.float64)
+        x0a = None if x0 is None else _f64(x0)
+        info = SolveInfo()
+        st = self.lib.pfv_solve(self._h, code, float(rtol), int(maxit), 0, _ptr(x0a, _dp), _ptr(x, _dp),
+                                C.byref(info))
+        out = {"iterations": info.iterations, "converged": bool(info.converged),
+               "rel_residual": info.rel_residual, "solve_ms": info.solve_ms}
+        if st != 0 and (raise_on_fail or st != 6):
+            self._check(st)
+        return x, out
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._check(self.lib.pfv_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def sync(self):
+        self._check(self.lib.pfv_sync(self._h))
+
+    def time_kernel(self, kernel: int, reps: int = 10) -> float:
+        """Average ms per launch (HIP events on the handle's stream); 0 SpMV(A), 1 node, 2 face."""
+        ms = C.c_double()
+        self._check(self.lib.pfv_time_kernel(self._h, int(kernel), int(reps), C.byref(ms)))
+        return ms.value

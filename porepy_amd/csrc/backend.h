@@ -1,0 +1,357 @@
+// backend.h — thin execution layer under the porefv kernels.
+//
+// Product build (hipcc --offload-arch=gfx950): kernels run on the MI355X; one HIP stream
+// per handle; rocprim for radix sort / scans; HIP events for phase timing.
+//
+// PFV_EMULATE build (plain g++, test infrastructure only, never shipped or loaded by
+// porepy_amd/): the SAME kernel bodies run sequentially on the host so that topology,
+// indexing and numerics of every kernel can be checked against the oracle in a container
+// without a GPU.  To make that possible kernels follow a discipline:
+//   * element kernels are lambdas over a flat index          -> pfv::parallel_for
+//   * cooperative kernels are written for ONE 64-lane wavefront per work item, as
+//     lane-strided loops (PFV_LANES) separated by w.sync(); values that cross a sync
+//     live in LDS (w.lds), never in per-lane registers         -> pfv::wave_for
+#pragma once
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#ifdef PFV_EMULATE
+#define PFV_HD
+#define PFV_LAMBDA [=]
+#define PFV_LANES(i, n) for (int i = 0; i < (int)(n); ++i)
+#else
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#define PFV_HD __host__ __device__
+#define PFV_LAMBDA [=] __device__
+#define PFV_LANES(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += 64)
+#endif
+
+namespace pfv {
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+
+constexpr int kWave = 64;
+
+#ifndef PFV_EMULATE
+#define PFV_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      throw ::pfv::Error(3, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+using stream_t = hipStream_t;
+#else
+using stream_t = int;
+#endif
+
+// ---------------------------------------------------------------- memory
+inline void* be_malloc(size_t bytes) {
+  if (bytes == 0) bytes = 8;
+#ifdef PFV_EMULATE
+  void* p = std::malloc(bytes);
+  if (!p) throw Error(3, "host emulation: out of memory");
+  return p;
+#else
+  void* p = nullptr;
+  PFV_HIP_CHECK(hipMalloc(&p, bytes));
+  return p;
+#endif
+}
+inline void be_free(void* p) {
+  if (!p) return;
+#ifdef PFV_EMULATE
+  std::free(p);
+#else
+  (void)hipFree(p);
+#endif
+}
+inline void be_h2d(void* dst, const void* src, size_t bytes, stream_t s) {
+  if (!bytes) return;
+#ifdef PFV_EMULATE
+  (void)s;
+  std::memcpy(dst, src, bytes);
+#else
+  PFV_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+  PFV_HIP_CHECK(hipStreamSynchronize(s));
+#endif
+}
+inline void be_d2h(void* dst, const void* src, size_t bytes, stream_t s) {
+  if (!bytes) return;
+#ifdef PFV_EMULATE
+  (void)s;
+  std::memcpy(dst, src, bytes);
+#else
+  PFV_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+  PFV_HIP_CHECK(hipStreamSynchronize(s));
+#endif
+}
+inline void be_d2d(void* dst, const void* src, size_t bytes, stream_t s) {
+  if (!bytes) return;
+#ifdef PFV_EMULATE
+  (void)s;
+  std::memmove(dst, src, bytes);
+#else
+  PFV_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+#endif
+}
+inline void be_memset(void* dst, int value, size_t bytes, stream_t s) {
+  if (!bytes) return;
+#ifdef PFV_EMULATE
+  (void)s;
+  std::memset(dst, value, bytes);
+#else
+  PFV_HIP_CHECK(hipMemsetAsync(dst, value, bytes, s));
+#endif
+}
+inline void be_sync(stream_t s) {
+#ifdef PFV_EMULATE
+  (void)s;
+#else
+  PFV_HIP_CHECK(hipStreamSynchronize(s));
+#endif
+}
+
+// growable device array
+template <class T>
+struct Buf {
+  T* p = nullptr;
+  size_t cap = 0;
+  Buf() = default;
+  Buf(const Buf&) = delete;
+  Buf& operator=(const Buf&) = delete;
+  ~Buf() { be_free(p); }
+  T* ensure(size_t n) {
+    if (n > cap) {
+      be_free(p);
+      p = nullptr;
+      cap = 0;
+      p = static_cast<T*>(be_malloc(n * sizeof(T)));
+      cap = n;
+    }
+    return p;
+  }
+  void release() {
+    be_free(p);
+    p = nullptr;
+    cap = 0;
+  }
+  operator T*() const { return p; }
+};
+
+// ---------------------------------------------------------------- timing
+struct Timer {
+#ifdef PFV_EMULATE
+  std::chrono::steady_clock::time_point t0;
+  void start(stream_t) { t0 = std::chrono::steady_clock::now(); }
+  double stop(stream_t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+#else
+  hipEvent_t a = nullptr, b = nullptr;
+  Timer() {
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+  }
+  ~Timer() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+  Timer(const Timer&) = delete;
+  void start(stream_t s) { PFV_HIP_CHECK(hipEventRecord(a, s)); }
+  double stop(stream_t s) {
+    PFV_HIP_CHECK(hipEventRecord(b, s));
+    PFV_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0.f;
+    PFV_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+  }
+#endif
+};
+
+// ---------------------------------------------------------------- launches
+struct WaveCtx {
+  int64_t item;  // work item this wavefront owns (node, face, cell, ...)
+  char* lds;     // LDS scratch for this wavefront (16-byte aligned)
+#ifdef PFV_EMULATE
+  bool lane0() const { return true; }
+  void sync() const {}
+#else
+  __device__ bool lane0() const { return threadIdx.x == 0; }
+  __device__ void sync() const { __syncthreads(); }
+#endif
+};
+
+#ifndef PFV_EMULATE
+template <class F>
+__global__ void __launch_bounds__(256) k_parallel_for(int64_t n, F f) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) f(i);
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_wave_for(int64_t n, F f) {
+  extern __shared__ __attribute__((aligned(16))) char pfv_lds[];
+  for (int64_t b = blockIdx.x; b < n; b += gridDim.x) {
+    WaveCtx w{b, pfv_lds};
+    f(w);
+    __syncthreads();
+  }
+}
+#endif
+
+// One thread per index.
+template <class F>
+inline void parallel_for(stream_t s, int64_t n, F f) {
+  if (n <= 0) return;
+#ifdef PFV_EMULATE
+  (void)s;
+  for (int64_t i = 0; i < n; ++i) f(i);
+#else
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;  // grid-stride beyond 64 blocks per CU
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_parallel_for<F>), dim3((unsigned)blocks), dim3(256), 0, s, n, f);
+  PFV_HIP_CHECK(hipGetLastError());
+#endif
+}
+
+// One 64-lane wavefront per work item, `lds_bytes` of LDS each.
+template <class F>
+inline void wave_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
+  if (n <= 0) return;
+  lds_bytes = (lds_bytes + 15) & ~size_t(15);
+#ifdef PFV_EMULATE
+  (void)s;
+  std::vector<double> lds((lds_bytes + 7) / 8 + 2);
+  for (int64_t b = 0; b < n; ++b) {
+    WaveCtx w{b, reinterpret_cast<char*>(lds.data())};
+    f(w);
+  }
+#else
+  if (lds_bytes > 160 * 1024) throw Error(5, "work item needs more than 160 KiB of LDS");
+  int64_t blocks = n;
+  // enough resident wavefronts to fill 256 CUs several times over, then grid-stride
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (lds_bytes > 48 * 1024) {
+    PFV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_for<F>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wave_for<F>), dim3((unsigned)blocks), dim3(64), lds_bytes, s, n, f);
+  PFV_HIP_CHECK(hipGetLastError());
+#endif
+}
+
+// ---------------------------------------------------------------- sort / scan
+struct Scratch {
+  Buf<char> tmp;
+};
+
+// stable sort of (key, value) pairs by the low `bits` bits of the key
+inline void sort_pairs(stream_t s, Scratch& sc, const uint32_t* kin, uint32_t* kout,
+                       const int32_t* vin, int32_t* vout, size_t n, int bits) {
+  if (n == 0) return;
+#ifdef PFV_EMULATE
+  (void)s; (void)sc; (void)bits;
+  std::vector<size_t> idx(n);
+  std::iota(idx.begin(), idx.end(), size_t(0));
+  std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return kin[a] < kin[b]; });
+  for (size_t i = 0; i < n; ++i) {
+    kout[i] = kin[idx[i]];
+    vout[i] = vin[idx[i]];
+  }
+#else
+  size_t bytes = 0;
+  PFV_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits, s));
+  sc.tmp.ensure(bytes);
+  PFV_HIP_CHECK(rocprim::radix_sort_pairs(sc.tmp.p, bytes, kin, kout, vin, vout, n, 0, bits, s));
+#endif
+}
+
+// out[i] = sum_{j<i} in[j] for i in [0, n]   (n+1 outputs; in[n] is not read)
+template <class TI, class TO>
+inline void exclusive_scan(stream_t s, Scratch& sc, const TI* in, TO* out, size_t n) {
+#ifdef PFV_EMULATE
+  (void)s; (void)sc;
+  TO acc = 0;
+  for (size_t i = 0; i < n; ++i) {
+    out[i] = acc;
+    acc += (TO)in[i];
+  }
+  out[n] = acc;
+#else
+  // scan n+1 entries of a transform iterator that yields 0 past the end
+  auto it = rocprim::make_transform_iterator(
+      rocprim::make_counting_iterator<size_t>(0),
+      [in, n] __device__(size_t i) -> TO { return i < n ? (TO)in[i] : TO(0); });
+  size_t bytes = 0;
+  PFV_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, it, out, TO(0), n + 1, rocprim::plus<TO>(), s));
+  sc.tmp.ensure(bytes);
+  PFV_HIP_CHECK(rocprim::exclusive_scan(sc.tmp.p, bytes, it, out, TO(0), n + 1, rocprim::plus<TO>(), s));
+#endif
+}
+
+template <class T>
+inline T read_scalar(stream_t s, const T* dptr) {
+  T v;
+  be_d2h(&v, dptr, sizeof(T), s);
+  return v;
+}
+
+// ---------------------------------------------------------------- small device helpers
+template <class T>
+PFV_HD inline int lower_bound_idx(const T* a, int n, T key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+PFV_HD inline void atomic_max_i32(int* addr, int v) {
+#ifdef PFV_EMULATE
+  if (v > *addr) *addr = v;
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicMax(addr, v);
+#else
+  (void)addr; (void)v;
+#endif
+#endif
+}
+PFV_HD inline void atomic_min_i32(int* addr, int v) {
+#ifdef PFV_EMULATE
+  if (v < *addr) *addr = v;
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicMin(addr, v);
+#else
+  (void)addr; (void)v;
+#endif
+#endif
+}
+PFV_HD inline void atomic_add_i32(int* addr, int v) {
+#ifdef PFV_EMULATE
+  *addr += v;
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicAdd(addr, v);
+#else
+  (void)addr; (void)v;
+#endif
+#endif
+}
+
+}  // namespace pfv

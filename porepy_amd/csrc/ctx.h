@@ -1,0 +1,107 @@
+// ctx.h — device-resident state behind a pfv_ctx handle.
+#pragma once
+#include "../../include/porefv.h"
+#include "backend.h"
+
+namespace pfv {
+
+constexpr int kMaxFaceNodes = 8;   // nodes per face supported by the merge kernels
+constexpr int kMaxCellFaces = 16;  // faces per cell supported by the A-pattern merge
+constexpr int kMaxBlock = 255;     // local sub-face / sub-cell indices are stored as uint8
+// block-size classes of the interaction-region kernel (one launch, one LDS size per class)
+static const int kClassBounds[] = {4, 8, 12, 16, 24, 32, 40, 48, 64, 96, 128, 192, 255};
+constexpr int kNumClasses = 13;
+
+struct CsrPattern {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  Buf<int32_t> indptr, indices;
+  int max_row = 0;
+};
+
+struct pfv_ctx_impl {
+  int device = 0;
+  stream_t stream{};
+  std::string err;
+  Scratch scratch;
+
+  // ---- grid (HBM, SoA [3][N]) ------------------------------------------------------
+  bool have_grid = false;
+  int nd = 0;
+  int64_t nc = 0, nf = 0, nn = 0, ncf = 0, nsf = 0;  // ncf = nnz(cell_faces), nsf = nnz(face_nodes)
+  Buf<double> nodes, fnorm, fcen, ccen, farea;
+  Buf<int32_t> cf_ptr, cf_idx, fn_ptr, fn_idx;
+  Buf<int8_t> cf_sgn;
+
+  // ---- parameters ---------------------------------------------------------------
+  bool have_params = false;
+  Buf<double> perm;   // [9][Nc]: perm[(3*i+j)*Nc + c] = K_ij(c)
+  Buf<uint8_t> bcflag;
+  Buf<double> robin;  // per face
+  double eta = 0.0;
+  bool have_eta_sub = false;
+  Buf<double> eta_sub;  // per subface (face_nodes CSC order)
+
+  // ---- sub-cell topology (SubcellTopology of the reference, node-major) ---------
+  bool have_topology = false;
+  int64_t nh = 0;             // sub-half-faces (cell, face, node)
+  Buf<int32_t> node_hptr;     // [nn+1] segment of each node in the h arrays
+  Buf<int32_t> h_cell;        // [nh] cell of h; h sorted by (node, cell, face)
+  Buf<uint8_t> h_lf;          // [nh] local index of h's face among the node's faces
+  Buf<int8_t> h_sgn;          // [nh] cell_faces sign
+  Buf<uint8_t> h_first;       // [nh] 1 if h is the side fluxes are evaluated from
+  Buf<int32_t> node_fptr;     // [nn+1] segment of each node in node_sf
+  Buf<int32_t> node_sf;       // [nsf] global subface ids (= face_nodes CSC positions), by (node, face)
+  Buf<int32_t> sf_face;       // [nsf] face of a subface
+  Buf<uint8_t> sf_ls;         // [nsf] local index of the subface within its node
+  Buf<int32_t> face_nsides;   // [nf] 1 = boundary face
+  Buf<int32_t> node_cells;    // [nh/nd] cells around each node, ascending (segment = node_hptr/nd)
+  Buf<int32_t> node_bptr;     // [nn+1] boundary faces around each node
+  Buf<int32_t> node_bfaces;   //   face ids, ascending
+  Buf<uint8_t> node_bls;      //   their local subface index
+  Buf<int64_t> node_mptr;     // [nn+1] prefix of n(v)^2: offset of the node's n x n blocks
+  Buf<int32_t> node_order;    // [nn] nodes sorted by block-size class
+  std::vector<int64_t> class_begin;  // host: first position of each size class in node_order
+  int max_block = 0, max_deg = 0;
+  int64_t sum_block_sq = 0;
+
+  // ---- per-node numeric results consumed by the face kernel ---------------------
+  Buf<double> Ainv, Tmat;     // [sum n^2] rows of A^-1 and of the flux operator T = W A^-1
+  Buf<double> h_bp;           // [nh]     cell-pressure rhs coefficient of h
+  Buf<double> h_bg;           // [nh*nd]  vector-source rhs coefficients of h
+  Buf<double> sf_sig;         // [nsf]    direct cell term of the subface flux
+  Buf<double> sf_nk;          // [nsf*nd] direct vector-source term
+  Buf<double> sf_beta;        // [nsf]    coefficient of the boundary value in the local rhs
+  Buf<uint8_t> sf_jstar;      // [nsf]    local subcell the flux is evaluated from
+  Buf<int32_t> status;        // [4] device status words: singular node, ...
+
+  // ---- outputs --------------------------------------------------------------------
+  bool have_symbolic = false, have_numeric = false, have_system = false;
+  CsrPattern pat_flux, pat_bound, pat_vs, pat_A;  // bound_pressure_* share flux / bound patterns
+  Buf<double> val[PFV_NUM_MATS];
+  bool filled[PFV_NUM_MATS] = {false, false, false, false, false, false, false};
+  Buf<double> rhs, diag, xsol, face_tmp, vec_in;
+  Buf<double> kry[10];
+  Buf<double> red;  // reduction partials
+
+  pfv_stats stats{};
+
+  const CsrPattern& pattern_of(int which) const {
+    switch (which) {
+      case PFV_MAT_FLUX:
+      case PFV_MAT_BOUND_PRESSURE_CELL:
+        return pat_flux;
+      case PFV_MAT_BOUND_FLUX:
+      case PFV_MAT_BOUND_PRESSURE_FACE:
+        return pat_bound;
+      case PFV_MAT_VECTOR_SOURCE:
+      case PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE:
+        return pat_vs;
+      default:
+        return pat_A;
+    }
+  }
+};
+
+}  // namespace pfv
+
+struct pfv_ctx : pfv::pfv_ctx_impl {};

@@ -1,0 +1,357 @@
+// porefv.hip — C ABI (include/porefv.h) of the MI355X-native MPFA-O assembly + solve.
+//
+// Build (product):   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC porefv.hip
+// Build (emulation): g++ -x c++ -DPFV_EMULATE -O2 -std=c++17 -shared -fPIC porefv.hip
+//                    (test infrastructure; see backend.h)
+#include <cmath>
+
+#include "ctx.h"
+#include "topology.inc"
+#include "mpfa_numeric.inc"
+#include "linalg.inc"
+
+using pfv::be_d2h;
+using pfv::be_h2d;
+using pfv::Error;
+
+namespace {
+
+template <class F>
+pfv_status guarded(pfv_ctx* h, F&& body) {
+  if (!h) return PFV_ERR_ARGUMENT;
+  try {
+#ifndef PFV_EMULATE
+    PFV_HIP_CHECK(hipSetDevice(h->device));
+#endif
+    body();
+    return PFV_OK;
+  } catch (const Error& e) {
+    h->err = e.what();
+    return (pfv_status)e.status;
+  } catch (const std::exception& e) {
+    h->err = e.what();
+    return PFV_ERR_HIP;
+  }
+}
+
+void require(bool ok, const char* msg) {
+  if (!ok) throw Error(PFV_ERR_ARGUMENT, msg);
+}
+
+template <class T>
+void upload(pfv::Buf<T>& buf, const T* host, size_t n, pfv::stream_t s) {
+  buf.ensure(n);
+  be_h2d(buf.p, host, n * sizeof(T), s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pfv_is_device_build(void) {
+#ifdef PFV_EMULATE
+  return 0;
+#else
+  return 1;
+#endif
+}
+
+pfv_status pfv_create(int device, pfv_ctx** out) {
+  if (!out) return PFV_ERR_ARGUMENT;
+  *out = nullptr;
+  pfv_ctx* h = nullptr;
+  try {
+    h = new pfv_ctx();
+    h->device = device;
+#ifndef PFV_EMULATE
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+      delete h;
+      return PFV_ERR_HIP;  // no GPU: the product library never falls back to the host
+    }
+    if (device < 0 || device >= count) {
+      delete h;
+      return PFV_ERR_ARGUMENT;
+    }
+    PFV_HIP_CHECK(hipSetDevice(device));
+    PFV_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+#endif
+  } catch (...) {
+    delete h;
+    return PFV_ERR_HIP;
+  }
+  *out = h;
+  return PFV_OK;
+}
+
+void pfv_destroy(pfv_ctx* h) {
+  if (!h) return;
+#ifndef PFV_EMULATE
+  (void)hipSetDevice(h->device);
+  if (h->stream) {
+    (void)hipStreamSynchronize(h->stream);
+  }
+  hipStream_t s = h->stream;
+  delete h;
+  if (s) (void)hipStreamDestroy(s);
+#else
+  delete h;
+#endif
+}
+
+const char* pfv_last_error(pfv_ctx* h) { return h ? h->err.c_str() : "null handle"; }
+
+pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, const double* nodes,
+                        const int32_t* cf_indptr, const int32_t* cf_indices, const int8_t* cf_sign,
+                        const int32_t* fn_indptr, const int32_t* fn_indices,
+                        const double* face_normals, const double* face_centers,
+                        const double* cell_centers, const double* face_areas) {
+  return guarded(h, [&] {
+    require(nd == 2 || nd == 3, "nd must be 2 or 3 (1-D grids use TPFA in the reference, mpfa.py:690-712)");
+    require(nc > 0 && nf > 0 && nn > 0, "empty grid");
+    require(nodes && cf_indptr && cf_indices && cf_sign && fn_indptr && fn_indices && face_normals &&
+                face_centers && cell_centers && face_areas,
+            "null grid array");
+    require(nc < (int64_t(1) << 31) && nf < (int64_t(1) << 31) && nn < (int64_t(1) << 31), "grid too large for int32 ids");
+    auto s = h->stream;
+    h->nd = nd;
+    h->nc = nc;
+    h->nf = nf;
+    h->nn = nn;
+    h->ncf = cf_indptr[nc];
+    h->nsf = fn_indptr[nf];
+    require(cf_indptr[0] == 0 && fn_indptr[0] == 0, "indptr must start at 0");
+    upload(h->nodes, nodes, 3 * (size_t)nn, s);
+    upload(h->fnorm, face_normals, 3 * (size_t)nf, s);
+    upload(h->fcen, face_centers, 3 * (size_t)nf, s);
+    upload(h->ccen, cell_centers, 3 * (size_t)nc, s);
+    upload(h->farea, face_areas, (size_t)nf, s);
+    upload(h->cf_ptr, cf_indptr, (size_t)nc + 1, s);
+    upload(h->cf_idx, cf_indices, (size_t)h->ncf, s);
+    upload(h->cf_sgn, cf_sign, (size_t)h->ncf, s);
+    upload(h->fn_ptr, fn_indptr, (size_t)nf + 1, s);
+    upload(h->fn_idx, fn_indices, (size_t)h->nsf, s);
+    h->have_grid = true;
+    h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
+    for (bool& f : h->filled) f = false;
+  });
+}
+
+pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t* bc_flags,
+                               const double* robin_weight, double eta, const double* eta_subface) {
+  return guarded(h, [&] {
+    require(h->have_grid, "pfv_set_grid must be called first");
+    require(perm_33n && bc_flags, "null parameter array");
+    auto s = h->stream;
+    upload(h->perm, perm_33n, 9 * (size_t)h->nc, s);
+    upload(h->bcflag, bc_flags, (size_t)h->nf, s);
+    if (robin_weight) {
+      upload(h->robin, robin_weight, (size_t)h->nf, s);
+    } else {
+      std::vector<double> ones((size_t)h->nf, 1.0);
+      upload(h->robin, ones.data(), ones.size(), s);
+    }
+    h->eta = eta;
+    h->have_eta_sub = eta_subface != nullptr;
+    if (eta_subface) upload(h->eta_sub, eta_subface, (size_t)h->nsf, s);
+    h->have_params = true;
+    h->have_numeric = h->have_system = false;
+  });
+}
+
+pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_params, "grid and parameters must be set before discretize");
+    auto s = h->stream;
+    pfv::Timer tm;
+    if (!h->have_topology || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
+      tm.start(s);
+      pfv::build_topology(*h);
+      h->stats.topology_ms = tm.stop(s);
+      tm.start(s);
+      pfv::build_symbolic(*h);
+      h->stats.symbolic_ms = tm.stop(s);
+    }
+    tm.start(s);
+    pfv::run_node_kernel(*h);
+    h->stats.node_ms = tm.stop(s);
+    const bool with_vs = !(flags & PFV_DISCR_SKIP_VECTOR_SOURCE);
+    tm.start(s);
+    pfv::run_face_kernel(*h, with_vs);
+    h->stats.face_ms = tm.stop(s);
+    h->have_numeric = true;
+    h->have_system = false;
+    h->filled[PFV_MAT_SYSTEM] = false;
+    double bytes = 0.0;
+    bytes += 2.0 * 8.0 * (double)h->pat_flux.nnz + 2.0 * 8.0 * (double)h->pat_bound.nnz;
+    if (with_vs) bytes += 2.0 * 8.0 * (double)h->pat_vs.nnz;
+    h->stats.bytes_written_outputs = bytes;
+  });
+}
+
+pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz) {
+  return guarded(h, [&] {
+    require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
+    require(h->have_symbolic, "discretize first");
+    const pfv::CsrPattern& P = h->pattern_of(which);
+    if (nrows) *nrows = P.nrows;
+    if (ncols) *ncols = P.ncols;
+    if (nnz) *nnz = P.nnz;
+  });
+}
+
+pfv_status pfv_get_matrix(pfv_ctx* h, int which, int32_t* indptr, int32_t* indices, double* data) {
+  return guarded(h, [&] {
+    require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
+    require(h->have_symbolic, "discretize first");
+    const pfv::CsrPattern& P = h->pattern_of(which);
+    auto s = h->stream;
+    if (indptr) be_d2h(indptr, P.indptr.p, sizeof(int32_t) * (size_t)(P.nrows + 1), s);
+    if (indices) be_d2h(indices, P.indices.p, sizeof(int32_t) * (size_t)P.nnz, s);
+    if (data) {
+      require(h->filled[which], "matrix values have not been computed");
+      be_d2h(data, h->val[which].p, sizeof(double) * (size_t)P.nnz, s);
+    }
+  });
+}
+
+pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* vector_source,
+                             const double* source) {
+  return guarded(h, [&] {
+    require(h->have_numeric, "discretize first");
+    require(bc_values != nullptr, "bc_values is required");
+    require(!vector_source || h->filled[PFV_MAT_VECTOR_SOURCE], "vector_source matrix was skipped");
+    auto s = h->stream;
+    pfv::Timer tm;
+    const size_t nf = (size_t)h->nf, nc = (size_t)h->nc;
+    double* in = h->vec_in.ensure(nf + nc * (size_t)h->nd + nc);
+    double* d_bc = in;
+    double* d_vs = vector_source ? in + nf : nullptr;
+    double* d_src = source ? in + nf + nc * (size_t)h->nd : nullptr;
+    be_h2d(d_bc, bc_values, nf * sizeof(double), s);
+    if (d_vs) be_h2d(d_vs, vector_source, nc * (size_t)h->nd * sizeof(double), s);
+    if (d_src) be_h2d(d_src, source, nc * sizeof(double), s);
+    tm.start(s);
+    if (!h->have_system) pfv::assemble_system(*h);
+    pfv::assemble_rhs(*h, d_bc, d_vs, d_src);
+    h->stats.assemble_ms = tm.stop(s);
+    h->have_system = true;
+  });
+}
+
+pfv_status pfv_get_rhs(pfv_ctx* h, double* b) {
+  return guarded(h, [&] {
+    require(h->have_system && b, "assemble first");
+    be_d2h(b, h->rhs.p, sizeof(double) * (size_t)h->nc, h->stream);
+  });
+}
+
+pfv_status pfv_spmv(pfv_ctx* h, int which, const double* x, double* y) {
+  return guarded(h, [&] {
+    require(which >= 0 && which < PFV_NUM_MATS && x && y, "bad argument");
+    require(h->have_symbolic && h->filled[which], "matrix values have not been computed");
+    const pfv::CsrPattern& P = h->pattern_of(which);
+    auto s = h->stream;
+    pfv::Buf<double> dx, dy;
+    dx.ensure((size_t)P.ncols);
+    dy.ensure((size_t)P.nrows);
+    be_h2d(dx.p, x, sizeof(double) * (size_t)P.ncols, s);
+    pfv::spmv(*h, P, h->val[which], dx.p, dy.p);
+    be_d2h(y, dy.p, sizeof(double) * (size_t)P.nrows, s);
+  });
+}
+
+pfv_status pfv_spmv_device(pfv_ctx* h, int which, const double* d_x, double* d_y) {
+  return guarded(h, [&] {
+    require(which >= 0 && which < PFV_NUM_MATS && d_x && d_y, "bad argument");
+    require(h->have_symbolic && h->filled[which], "matrix values have not been computed");
+    pfv::spmv(*h, h->pattern_of(which), h->val[which], d_x, d_y);
+  });
+}
+
+pfv_status pfv_get_device_rhs(pfv_ctx* h, double** d_b, double** d_diag) {
+  return guarded(h, [&] {
+    require(h->have_system, "assemble first");
+    if (d_b) *d_b = h->rhs.p;
+    if (d_diag) *d_diag = h->diag.p;
+  });
+}
+
+pfv_status pfv_sync(pfv_ctx* h) {
+  return guarded(h, [&] { pfv::be_sync(h->stream); });
+}
+
+pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart, const double* x0,
+                     double* x, pfv_solve_info* info) {
+  (void)restart;
+  pfv::SolveResult res;
+  pfv_status st = guarded(h, [&] {
+    require(h->have_system, "assemble first");
+    require(x != nullptr, "x is required");
+    require(method == PFV_SOLVE_CG || method == PFV_SOLVE_BICGSTAB,
+            "method must be PFV_SOLVE_CG or PFV_SOLVE_BICGSTAB");
+    require(rtol > 0 && maxit > 0, "rtol and maxit must be positive");
+    auto s = h->stream;
+    const size_t n = (size_t)h->nc;
+    double* dx = h->xsol.ensure(n);
+    if (x0) be_h2d(dx, x0, n * sizeof(double), s); else pfv::be_memset(dx, 0, n * sizeof(double), s);
+    pfv::Timer tm;
+    tm.start(s);
+    res = pfv::krylov_solve(*h, method, rtol, maxit, h->rhs.p, dx, x0 == nullptr);
+    h->stats.solve_ms = tm.stop(s);
+    be_d2h(x, dx, n * sizeof(double), s);
+  });
+  if (info) {
+    info->iterations = res.iterations;
+    info->converged = res.converged ? 1 : 0;
+    info->rel_residual = res.relres;
+    info->solve_ms = h ? h->stats.solve_ms : 0.0;
+  }
+  if (st == PFV_OK && !res.converged) {
+    h->err = "Krylov solver did not reach the requested tolerance";
+    return PFV_ERR_NOT_CONVERGED;
+  }
+  return st;
+}
+
+pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out) {
+  return guarded(h, [&] {
+    require(out != nullptr, "null output");
+    *out = h->stats;
+  });
+}
+
+pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms) {
+  return guarded(h, [&] {
+    require(avg_ms != nullptr && reps > 0, "bad argument");
+    auto s = h->stream;
+    pfv::Timer tm;
+    if (kernel == PFV_KERNEL_SPMV_A) {
+      require(h->have_system, "assemble first");
+      const size_t n = (size_t)h->nc;
+      double* x = h->kry[7].ensure(n);
+      double* y = h->kry[8].ensure(n);
+      pfv::be_d2d(x, h->rhs.p, n * sizeof(double), s);
+      pfv::spmv(*h, h->pat_A, h->val[PFV_MAT_SYSTEM], x, y);
+      tm.start(s);
+      for (int i = 0; i < reps; ++i) pfv::spmv(*h, h->pat_A, h->val[PFV_MAT_SYSTEM], x, y);
+      *avg_ms = tm.stop(s) / reps;
+    } else if (kernel == PFV_KERNEL_NODE) {
+      require(h->have_numeric, "discretize first");
+      tm.start(s);
+      for (int i = 0; i < reps; ++i) pfv::run_node_kernel(*h);
+      *avg_ms = tm.stop(s) / reps;
+    } else if (kernel == PFV_KERNEL_FACE) {
+      require(h->have_numeric, "discretize first");
+      const bool with_vs = h->filled[PFV_MAT_VECTOR_SOURCE];
+      tm.start(s);
+      for (int i = 0; i < reps; ++i) pfv::run_face_kernel(*h, with_vs);
+      *avg_ms = tm.stop(s) / reps;
+    } else {
+      require(false, "unknown kernel id");
+    }
+  });
+}
+
+}  // extern "C"

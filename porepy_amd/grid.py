@@ -1,0 +1,388 @@
+"""Minimal grid container + structured generators feeding the MPFA hot path.
+
+The discretization only reads plain arrays from a grid (the fields of the reference's
+``pp.Grid``, grids/grid.py:78-272).  This module gives the same attribute names so a
+``porepy_amd.Grid`` and a reference ``pp.Grid`` are interchangeable at the boundary
+(duck typing, see ``grid_to_raw``), and provides generators for the synthetic box grids the
+benchmark configurations use (BASELINE.json: Cartesian 2-D/3-D, structured simplex boxes).
+Cell/face/node numbering of the generators is this package's own; it is not the
+reference's numbering (the golden fixtures carry the reference's grids as raw arrays).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sps
+
+
+class Grid:
+    """Cells / faces / nodes with the attribute names of the reference grid class.
+
+    nodes (3, Nn); face_nodes csc bool (Nn x Nf); cell_faces csc int (Nf x Nc), data +-1 with
+    +1 meaning the stored face normal points out of the cell (grids/grid.py:106-114).
+    """
+
+    def __init__(self, dim: int, nodes: np.ndarray, face_nodes, cell_faces, name: str):
+        self.dim = int(dim)
+        self.nodes = np.asarray(nodes, dtype=float)
+        self.face_nodes = sps.csc_matrix(face_nodes)
+        self.cell_faces = sps.csc_matrix(cell_faces)
+        self.face_nodes.sort_indices()
+        self.cell_faces.sort_indices()
+        self.name = name
+        self.num_nodes = self.nodes.shape[1]
+        self.num_faces = self.face_nodes.shape[1]
+        self.num_cells = self.cell_faces.shape[1]
+        self.tags: dict = {}
+        self._fn_ordered = None  # optional (Nf, k) cyclic node order of polygonal faces
+        self._update_boundary_tags()
+
+    # ---- topology helpers -------------------------------------------------------------
+    def _update_boundary_tags(self):
+        sides = np.bincount(self.cell_faces.indices, minlength=self.num_faces)
+        self.tags["domain_boundary_faces"] = sides == 1
+        self.tags.setdefault("fracture_faces", np.zeros(self.num_faces, dtype=bool))
+        self.tags.setdefault("tip_faces", np.zeros(self.num_faces, dtype=bool))
+        bn = np.zeros(self.num_nodes, dtype=bool)
+        fn = self.face_nodes
+        for f in np.flatnonzero(sides == 1):
+            bn[fn.indices[fn.indptr[f]: fn.indptr[f + 1]]] = True
+        self.tags["domain_boundary_nodes"] = bn
+
+    def get_all_boundary_faces(self) -> np.ndarray:
+        t = self.tags
+        return np.flatnonzero(t["domain_boundary_faces"] | t["fracture_faces"] | t["tip_faces"])
+
+    def get_boundary_faces(self) -> np.ndarray:
+        return np.flatnonzero(self.tags["domain_boundary_faces"])
+
+    def get_internal_faces(self) -> np.ndarray:
+        return np.setdiff1d(np.arange(self.num_faces), self.get_all_boundary_faces())
+
+    def cell_nodes(self):
+        return ((self.face_nodes.astype(int) @ abs(self.cell_faces).astype(int)) > 0).tocsc()
+
+    def divergence(self, dim: int = 1):
+        """cell_faces^T (kron identity for vector problems), grids/grid.py:1237-1266."""
+        if dim == 1:
+            return self.cell_faces.T.tocsr()
+        return sps.kron(self.cell_faces, sps.eye(dim)).T.tocsr()
+
+    def copy(self):
+        g = Grid(self.dim, self.nodes.copy(), self.face_nodes.copy(), self.cell_faces.copy(), self.name)
+        for k in ("face_normals", "face_areas", "face_centers", "cell_centers", "cell_volumes"):
+            if hasattr(self, k):
+                setattr(g, k, getattr(self, k).copy())
+        g.tags = {k: np.copy(v) for k, v in self.tags.items()}
+        g._fn_ordered = self._fn_ordered
+        return g
+
+    # ---- geometry -----------------------------------------------------------------------
+    def compute_geometry(self):
+        """Face normals/areas/centers and cell centers/volumes for 2-D polygons and 3-D
+        cells with planar convex faces; normals are oriented to agree with cell_faces."""
+        if self.dim == 2:
+            self._geometry_2d()
+        elif self.dim == 3:
+            self._geometry_3d()
+        else:
+            raise NotImplementedError("porepy_amd grids are 2-D or 3-D")
+        # orient normals: sign(c, f) * n_f . (x_f - x_c) > 0
+        cf = self.cell_faces
+        cell_of = np.repeat(np.arange(self.num_cells), np.diff(cf.indptr))
+        first = np.full(self.num_faces, -1)
+        first[cf.indices[::-1]] = np.arange(cf.indices.size)[::-1]  # first entry of each face
+        e = first
+        out = self.face_centers[:, cf.indices[e]] - self.cell_centers[:, cell_of[e]]
+        s = np.sign(np.sum(self.face_normals * out, axis=0)) * cf.data[e]
+        self.face_normals = self.face_normals * np.where(s < 0, -1.0, 1.0)
+
+    def _geometry_2d(self):
+        fn = self.face_nodes
+        if not np.all(np.diff(fn.indptr) == 2):
+            raise ValueError("2-D faces must have two nodes")
+        x = self.nodes
+        a = x[:, fn.indices[0::2]]
+        b = x[:, fn.indices[1::2]]
+        t = b - a
+        self.face_areas = np.sqrt(np.sum(t * t, axis=0))
+        self.face_centers = 0.5 * (a + b)
+        self.face_normals = np.vstack((t[1], -t[0], np.zeros(self.num_faces)))
+        cf = self.cell_faces
+        cell_of = np.repeat(np.arange(self.num_cells), np.diff(cf.indptr))
+        nfc = np.diff(cf.indptr).astype(float)
+        c0 = np.vstack([np.bincount(cell_of, self.face_centers[d, cf.indices], self.num_cells) / nfc
+                        for d in range(3)])
+        pa, pb = a[:, cf.indices] - c0[:, cell_of], b[:, cf.indices] - c0[:, cell_of]
+        ar = 0.5 * np.abs(pa[0] * pb[1] - pa[1] * pb[0])
+        cen = c0[:, cell_of] + (pa + pb) / 3.0
+        vol = np.bincount(cell_of, ar, self.num_cells)
+        self.cell_volumes = vol
+        self.cell_centers = np.vstack([np.bincount(cell_of, ar * cen[d], self.num_cells) / vol
+                                       for d in range(3)])
+
+    def _ordered_face_nodes(self):
+        fn = self.face_nodes
+        k = np.diff(fn.indptr)
+        if not np.all(k == k[0]):
+            raise NotImplementedError("faces with differing node counts")
+        k = int(k[0])
+        idx = fn.indices.reshape(self.num_faces, k)
+        if k == 3:
+            return idx
+        if self._fn_ordered is not None:
+            return self._fn_ordered
+        p = self.nodes[:, idx]  # (3, Nf, k)
+        c = p.mean(axis=2, keepdims=True)
+        r = p - c
+        u = r[:, :, 0] / np.linalg.norm(r[:, :, 0], axis=0)
+        crosses = np.cross(r[:, :, [0]], r[:, :, 1:], axis=0)  # (3, Nf, k-1)
+        best = np.argmax(np.sum(crosses**2, axis=0), axis=1)
+        n = np.take_along_axis(crosses, best[None, :, None], axis=2)[:, :, 0]
+        n /= np.linalg.norm(n, axis=0)
+        w = np.cross(n, u, axis=0)
+        ang = np.arctan2(np.einsum("dfk,df->fk", r, w), np.einsum("dfk,df->fk", r, u))
+        order = np.argsort(ang, axis=1)
+        return np.take_along_axis(idx, order, axis=1)
+
+    def _geometry_3d(self):
+        idx = self._ordered_face_nodes()
+        nf, k = idx.shape
+        p = self.nodes[:, idx]  # (3, Nf, k)
+        c = p.mean(axis=2)
+        q = np.roll(p, -1, axis=2)
+        tri_n = 0.5 * np.cross(p - c[:, :, None], q - c[:, :, None], axis=0)  # (3, Nf, k)
+        tri_a = np.linalg.norm(tri_n, axis=0)
+        self.face_normals = tri_n.sum(axis=2)
+        self.face_areas = tri_a.sum(axis=1)
+        tri_c = (c[:, :, None] + p + q) / 3.0
+        self.face_centers = (tri_c * tri_a[None]).sum(axis=2) / self.face_areas
+        cf = self.cell_faces
+        cell_of = np.repeat(np.arange(self.num_cells), np.diff(cf.indptr))
+        nfc = np.diff(cf.indptr).astype(float)
+        c0 = np.vstack([np.bincount(cell_of, self.face_centers[d, cf.indices], self.num_cells) / nfc
+                        for d in range(3)])
+        vol = np.zeros(self.num_cells)
+        mom = np.zeros((3, self.num_cells))
+        o = c0[:, cell_of]
+        fc_ = c[:, cf.indices]
+        for i in range(k):
+            a = p[:, cf.indices, i] - o
+            b = q[:, cf.indices, i] - o
+            d = fc_ - o
+            v = np.abs(np.sum(a * np.cross(b, d, axis=0), axis=0)) / 6.0
+            cen = o + (a + b + d) / 4.0
+            vol += np.bincount(cell_of, v, self.num_cells)
+            for dd in range(3):
+                mom[dd] += np.bincount(cell_of, v * cen[dd], self.num_cells)
+        self.cell_volumes = vol
+        self.cell_centers = mom / vol
+
+
+# ------------------------------------------------------------------------------------------
+def _lattice_nodes(nx, physdims):
+    nx = np.asarray(nx, dtype=int)
+    physdims = np.asarray(nx if physdims is None else physdims, dtype=float)
+    axes = [np.linspace(0.0, physdims[d], nx[d] + 1) for d in range(nx.size)]
+    if nx.size == 2:
+        X, Y = np.meshgrid(axes[0], axes[1], indexing="ij")
+        pts = np.vstack((X.ravel("F"), Y.ravel("F"), np.zeros(X.size)))
+    else:
+        X, Y, Z = np.meshgrid(axes[0], axes[1], axes[2], indexing="ij")
+        pts = np.vstack((X.ravel("F"), Y.ravel("F"), Z.ravel("F")))
+    return nx, pts
+
+
+def _csc_from_columns(cols: np.ndarray, nrows: int, data=None):
+    """cols: (ncols, k) row indices of each column."""
+    ncols, k = cols.shape
+    indptr = np.arange(0, (ncols + 1) * k, k)
+    d = np.ones(cols.size, dtype=bool) if data is None else data.ravel()
+    m = sps.csc_matrix((d, cols.ravel(), indptr), shape=(nrows, ncols))
+    m.sort_indices()
+    return m
+
+
+class CartGrid(Grid):
+    """Cartesian grid of nx cells on the box [0, physdims]; x runs fastest."""
+
+    def __init__(self, nx, physdims=None):
+        nx, pts = _lattice_nodes(nx, physdims)
+        dim = nx.size
+        if dim == 2:
+            n0, n1 = nx
+            nid = lambda i, j: i + (n0 + 1) * j  # noqa: E731
+            I, J = np.meshgrid(np.arange(n0 + 1), np.arange(n1), indexing="ij")
+            fx = np.stack((nid(I, J).ravel("F"), nid(I, J + 1).ravel("F")), 1)
+            I2, J2 = np.meshgrid(np.arange(n0), np.arange(n1 + 1), indexing="ij")
+            fy = np.stack((nid(I2, J2).ravel("F"), nid(I2 + 1, J2).ravel("F")), 1)
+            fnodes = np.vstack((fx, fy))
+            nfx = (n0 + 1) * n1
+            Ic, Jc = np.meshgrid(np.arange(n0), np.arange(n1), indexing="ij")
+            Ic, Jc = Ic.ravel("F"), Jc.ravel("F")
+            west = Ic + (n0 + 1) * Jc
+            east = west + 1
+            south = nfx + Ic + n0 * Jc
+            north = south + n0
+            cfaces = np.stack((west, east, south, north), 1)
+            sgn = np.tile(np.array([-1, 1, -1, 1]), (cfaces.shape[0], 1))
+            ordered = None
+        elif dim == 3:
+            n0, n1, n2 = nx
+            nid = lambda i, j, k: i + (n0 + 1) * (j + (n1 + 1) * k)  # noqa: E731
+            I, J, K = [a.ravel("F") for a in np.meshgrid(np.arange(n0 + 1), np.arange(n1), np.arange(n2), indexing="ij")]
+            fx = np.stack((nid(I, J, K), nid(I, J + 1, K), nid(I, J + 1, K + 1), nid(I, J, K + 1)), 1)
+            I, J, K = [a.ravel("F") for a in np.meshgrid(np.arange(n0), np.arange(n1 + 1), np.arange(n2), indexing="ij")]
+            fy = np.stack((nid(I, J, K), nid(I + 1, J, K), nid(I + 1, J, K + 1), nid(I, J, K + 1)), 1)
+            I, J, K = [a.ravel("F") for a in np.meshgrid(np.arange(n0), np.arange(n1), np.arange(n2 + 1), indexing="ij")]
+            fz = np.stack((nid(I, J, K), nid(I + 1, J, K), nid(I + 1, J + 1, K), nid(I, J + 1, K)), 1)
+            fnodes = np.vstack((fx, fy, fz))
+            nfx, nfy = (n0 + 1) * n1 * n2, n0 * (n1 + 1) * n2
+            I, J, K = [a.ravel("F") for a in np.meshgrid(np.arange(n0), np.arange(n1), np.arange(n2), indexing="ij")]
+            west = I + (n0 + 1) * (J + n1 * K)
+            south = nfx + I + n0 * (J + (n1 + 1) * K)
+            bottom = nfx + nfy + I + n0 * (J + n1 * K)
+            cfaces = np.stack((west, west + 1, south, south + n0, bottom, bottom + n0 * n1), 1)
+            sgn = np.tile(np.array([-1, 1, -1, 1, -1, 1]), (cfaces.shape[0], 1))
+            ordered = fnodes
+        else:
+            raise NotImplementedError("CartGrid: 2-D or 3-D")
+        face_nodes = _csc_from_columns(fnodes, pts.shape[1])
+        order = np.argsort(cfaces, axis=1)
+        cfaces = np.take_along_axis(cfaces, order, 1)
+        sgn = np.take_along_axis(sgn, order, 1)
+        cell_faces = _csc_from_columns(cfaces, fnodes.shape[0], sgn.astype(int))
+        super().__init__(dim, pts, face_nodes, cell_faces, "CartGrid")
+        self._fn_ordered = ordered
+        self.cart_dims = nx
+
+
+def _simplex_grid(dim, pts, cells, name):
+    """Faces, cell_faces (signs from geometry in compute_geometry) of a conforming simplex mesh.
+    cells: (Nc, dim+1) node ids."""
+    nn = pts.shape[1]
+    nc = cells.shape[0]
+    k = dim  # nodes per face
+    loc = [np.delete(np.arange(dim + 1), i) for i in range(dim + 1)]
+    allf = np.sort(np.concatenate([cells[:, l] for l in loc], axis=0), axis=1)  # ((dim+1)*Nc, k)
+    key = allf[:, 0].astype(np.int64)
+    for d in range(1, k):
+        key = key * nn + allf[:, d]
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    fnodes = allf[first]
+    nf = fnodes.shape[0]
+    cfaces = inv.reshape(dim + 1, nc).T  # face ids of each cell
+    order = np.argsort(cfaces, axis=1)
+    cfaces = np.take_along_axis(cfaces, order, 1)
+    face_nodes = _csc_from_columns(fnodes, nn)
+    # provisional signs (+1); fixed below from geometry
+    g = Grid.__new__(Grid)
+    cell_faces = _csc_from_columns(cfaces, nf, np.ones(cfaces.shape, dtype=int))
+    Grid.__init__(g, dim, pts, face_nodes, cell_faces, name)
+    return g
+
+
+def _fix_simplex_signs(g: Grid):
+    """Normal of a face points from its lower-numbered to its higher-numbered cell side as
+    given by the sorted node order; signs follow from geometry."""
+    cf = g.cell_faces
+    x = g.nodes
+    fn = g.face_nodes
+    k = g.dim
+    idx = fn.indices.reshape(g.num_faces, k)
+    if k == 2:
+        t = x[:, idx[:, 1]] - x[:, idx[:, 0]]
+        n = np.vstack((t[1], -t[0], np.zeros(g.num_faces)))
+    else:
+        n = np.cross(x[:, idx[:, 1]] - x[:, idx[:, 0]], x[:, idx[:, 2]] - x[:, idx[:, 0]], axis=0)
+    fc = x[:, idx].mean(axis=2)
+    cell_of = np.repeat(np.arange(g.num_cells), np.diff(cf.indptr))
+    nodes_of_cell = None
+    # cell centroid = mean of its dim+1 nodes = (sum of face centers * k - ...) -> use faces
+    cc = np.vstack([np.bincount(cell_of, fc[d, cf.indices], g.num_cells) / (k + 1) for d in range(3)])
+    s = np.sign(np.sum(n[:, cf.indices] * (fc[:, cf.indices] - cc[:, cell_of]), axis=0))
+    g.cell_faces = sps.csc_matrix((s.astype(int), cf.indices, cf.indptr), shape=cf.shape)
+    del nodes_of_cell
+
+
+class StructuredTriangleGrid(Grid):
+    """Each cell of an nx x ny lattice split into two triangles."""
+
+    def __init__(self, nx, physdims=None):
+        nx, pts = _lattice_nodes(nx, physdims)
+        n0, n1 = nx
+        I, J = [a.ravel("F") for a in np.meshgrid(np.arange(n0), np.arange(n1), indexing="ij")]
+        nid = lambda i, j: i + (n0 + 1) * j  # noqa: E731
+        a, b, c, d = nid(I, J), nid(I + 1, J), nid(I, J + 1), nid(I + 1, J + 1)
+        cells = np.vstack((np.stack((a, b, d), 1), np.stack((a, d, c), 1)))
+        g = _simplex_grid(2, pts, cells, "StructuredTriangleGrid")
+        _fix_simplex_signs(g)
+        self.__dict__.update(g.__dict__)
+
+
+class StructuredTetrahedralGrid(Grid):
+    """Each cell of an nx x ny x nz lattice split into six tetrahedra (Kuhn subdivision,
+    conforming across lattice cells): 6 * nx*ny*nz cells."""
+
+    def __init__(self, nx, physdims=None):
+        nx, pts = _lattice_nodes(nx, physdims)
+        n0, n1, n2 = nx
+        I, J, K = [a.ravel("F") for a in np.meshgrid(np.arange(n0), np.arange(n1), np.arange(n2), indexing="ij")]
+        nid = lambda i, j, k: i + (n0 + 1) * (j + (n1 + 1) * k)  # noqa: E731
+        import itertools
+
+        tets = []
+        for perm in itertools.permutations(range(3)):
+            off = np.zeros(3, dtype=int)
+            verts = [nid(I, J, K)]
+            for ax in perm:
+                off[ax] = 1
+                verts.append(nid(I + off[0], J + off[1], K + off[2]))
+            tets.append(np.stack(verts, 1))
+        cells = np.vstack(tets)
+        g = _simplex_grid(3, pts, cells, "StructuredTetrahedralGrid")
+        _fix_simplex_signs(g)
+        self.__dict__.update(g.__dict__)
+
+
+def perturb_interior_nodes(g: Grid, rate: float, seed: int = 1) -> Grid:
+    """nodes += (U(0,1) - 0.5) * rate on nodes strictly inside the bounding box, then
+    recompute geometry (the synthetic 'unstructured-like' grids of SURVEY 8(d))."""
+    rng = np.random.default_rng(seed)
+    x = g.nodes
+    d = g.dim
+    lo, hi = x[:d].min(axis=1, keepdims=True), x[:d].max(axis=1, keepdims=True)
+    tol = 1e-9 * (hi - lo)
+    interior = np.all((x[:d] > lo + tol) & (x[:d] < hi - tol), axis=0)
+    x = x.copy()
+    x[:d, interior] += (rng.random((d, int(interior.sum()))) - 0.5) * rate
+    g.nodes = x
+    g.compute_geometry()
+    return g
+
+
+def grid_to_raw(g) -> dict:
+    """Flatten a grid (this package's or the reference's pp.Grid) into the arrays that
+    cross the C ABI (include/porefv.h: pfv_set_grid)."""
+    cf = sps.csc_matrix(g.cell_faces)
+    cf.sort_indices()
+    fn = sps.csc_matrix(g.face_nodes)
+    fn.sort_indices()
+    frac = np.zeros(g.num_faces, dtype=bool)
+    if "fracture_faces" in getattr(g, "tags", {}):
+        frac |= np.asarray(g.tags["fracture_faces"], dtype=bool)
+    return {
+        "dim": int(g.dim),
+        "name": str(getattr(g, "name", "")),
+        "nodes": np.ascontiguousarray(g.nodes, dtype=np.float64),
+        "cf_indptr": cf.indptr.astype(np.int32),
+        "cf_indices": cf.indices.astype(np.int32),
+        "cf_sign": np.asarray(cf.data).astype(np.int8),
+        "fn_indptr": fn.indptr.astype(np.int32),
+        "fn_indices": fn.indices.astype(np.int32),
+        "face_normals": np.ascontiguousarray(g.face_normals, dtype=np.float64),
+        "face_centers": np.ascontiguousarray(g.face_centers, dtype=np.float64),
+        "cell_centers": np.ascontiguousarray(g.cell_centers, dtype=np.float64),
+        "face_areas": np.ascontiguousarray(g.face_areas, dtype=np.float64),
+        "cell_volumes": np.ascontiguousarray(g.cell_volumes, dtype=np.float64),
+        "fracture_faces": frac,
+    }

@@ -1,0 +1,167 @@
+"""Parity checks shared by the CPU (host-emulation build) and GPU (product build) suites.
+The library under test is driven through the C ABI; the oracle / golden fixtures check it."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import scipy.sparse.linalg as spla
+
+import porepy_amd as pa
+from oracle import mpfa_oracle as mo
+from tests._golden import ALL_KEYS, Case, check_pattern, rel_max_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMUL_SO = os.path.join(ROOT, "oracle", "_build", "libporefv_emul.so")
+TOL = 1e-10  # north_star: matrix entries and fields within 1e-10 relative
+WHICH = dict(zip(ALL_KEYS, range(6)))
+
+
+def emulation_library():
+    """Host-emulation build of porepy_amd/csrc (same kernel sources, sequential lanes)."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+
+    if ge._stale(EMUL_SO):
+        os.makedirs(os.path.dirname(EMUL_SO), exist_ok=True)
+        subprocess.run(["g++", "-x", "c++", "-DPFV_EMULATE", "-O2", "-std=c++17", "-shared", "-fPIC",
+                        "-Wno-maybe-uninitialized", "porefv.hip", "-o", EMUL_SO],
+                       check=True, cwd=os.path.join(ROOT, "porepy_amd", "csrc"))
+    return pa._lib.load_library(EMUL_SO)
+
+
+def flags_of(bc: dict) -> np.ndarray:
+    return (bc["is_dir"] * 1 + bc["is_neu"] * 2 + bc["is_rob"] * 4 + bc["is_internal"] * 8).astype(np.uint8)
+
+
+def run_case(lib, c: Case):
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(c.grid)
+    eta = c.eta if c.eta is not None else mo.default_eta(c.grid["name"])
+    ctx.set_params(c.perm, flags_of(c.bc), c.bc["robin_weight"], eta)
+    ctx.discretize()
+    return ctx
+
+
+def check_golden_case(lib, name: str):
+    c = Case(name)
+    ctx = run_case(lib, c)
+    ora = mo.discretize(c.grid, c.perm, c.bc, eta=c.eta)
+    for k in ALL_KEYS:
+        M = ctx.matrix(WHICH[k])
+        assert M.indices.dtype == np.int32 and M.has_sorted_indices
+        # pattern: bit-exact against the oracle's structural stencil
+        assert np.array_equal(M.indptr, ora[k].indptr), (name, k)
+        assert np.array_equal(M.indices, ora[k].indices), (name, k)
+        assert rel_max_err(M, ora[k]) < TOL, (name, k)
+        if k in c.ref:  # and against what the reference itself produced
+            assert rel_max_err(M, c.ref[k]) < TOL, (name, k)
+            subset, outside, _ = check_pattern(M, c.ref[k])
+            assert subset and outside < 1e-12, (name, k, outside)
+    ctx.assemble(c.bc_values, c.vector_source_values, c.source)
+    A, b = ctx.matrix(6), ctx.rhs()
+    assert rel_max_err(A, c.ref["A"]) < TOL
+    assert np.linalg.norm(b - c.ref_rhs) <= TOL * np.linalg.norm(c.ref_rhs)
+    x, info = ctx.solve("bicgstab", rtol=1e-13, maxit=5000)
+    assert info["converged"]
+    # field: residual in the REFERENCE system, and the field itself where A is well conditioned
+    res = np.linalg.norm(c.ref_rhs - c.ref["A"] @ x) / np.linalg.norm(c.ref_rhs)
+    assert res < 1e-11, (name, res)
+    if "hetero" not in name:
+        assert np.linalg.norm(x - c.ref_x) <= TOL * np.linalg.norm(c.ref_x), name
+    # flux post-processing through the device SpMV
+    fl = ctx.spmv(0, x) + ctx.spmv(1, c.bc_values)
+    fl_ref = c.ref["flux"] @ c.ref_x + c.ref["bound_flux"] @ c.bc_values
+    assert np.linalg.norm(fl - fl_ref) <= 1e-9 * max(np.linalg.norm(fl_ref), 1e-300)
+    ctx.close()
+
+
+def check_generic_pattern_bit_exact(lib):
+    c = Case("tet_2x2x2_dir_generic")
+    ctx = run_case(lib, c)
+    for k in ("flux", "bound_flux", "vector_source"):
+        M = ctx.matrix(WHICH[k])
+        assert np.array_equal(M.indptr, c.ref[k].indptr), k
+        assert np.array_equal(M.indices, c.ref[k].indices), k
+    ctx.assemble(c.bc_values, None, c.source)
+    A = ctx.matrix(6)
+    assert np.array_equal(A.indptr, c.ref["A"].indptr) and np.array_equal(A.indices, c.ref["A"].indices)
+
+
+def check_known_answer(lib, key: str):
+    """The reference's own golden vectors (tests/numerics/fv/test_mpfa.py:224-250)."""
+    c = Case("known_" + key)
+    ctx = run_case(lib, c)
+    ctx.assemble(c.bc_values, None, c.source)
+    u, info = ctx.solve("bicgstab", rtol=1e-13, maxit=5000)
+    flux = ctx.spmv(0, u) + ctx.spmv(1, c.bc_values)
+    assert np.allclose(u, c.known_u)
+    assert np.allclose(flux, c.known_flux)
+
+
+def operator_roundtrip(lib, g, seed=0, kinds=("dir", "neu", "rob"), hetero=1.0):
+    """Mpfa operator API on one of this package's grids, compared with the oracle."""
+    rng = np.random.default_rng(seed)
+    nc = g.num_cells
+    kk = np.where(g.cell_centers[0] > 0.5 * g.nodes[0].max(), hetero, 1.0)
+    kw = dict(kxx=kk * (1 + rng.random(nc)), kyy=kk * (2 + rng.random(nc)), kxy=kk * 0.3 * rng.random(nc))
+    if g.dim == 3:
+        kw.update(kzz=kk * (0.5 + rng.random(nc)), kxz=kk * 0.1 * rng.random(nc), kyz=kk * 0.1 * rng.random(nc))
+    K = pa.SecondOrderTensor(**kw)
+    bf = g.get_all_boundary_faces()
+    bc = pa.BoundaryCondition(g, bf, list(np.array(kinds)[np.arange(bf.size) % len(kinds)]))
+    bc.robin_weight = 0.7 + rng.random(g.num_faces)
+    bv = np.zeros(g.num_faces)
+    bv[bf] = rng.random(bf.size) - 0.4
+    gv = rng.random(nc * g.dim) - 0.5
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": bv,
+                                           "vector_source": gv})
+    discr = pa.Mpfa("flow", library=lib)
+    discr.discretize(g, data)
+    raw = pa.grid_to_raw(g)
+    ora = mo.discretize(raw, K.values, pa.bc_to_raw(bc))
+    mats = data[pa.DISCRETIZATION_MATRICES]["flow"]
+    for k in ALL_KEYS:
+        assert np.array_equal(mats[k].indices, ora[k].indices), k
+        assert rel_max_err(mats[k], ora[k]) < TOL, k
+    A, b = discr.assemble_matrix_rhs(g, data)
+    Ao, bo = mo.assemble_matrix_rhs(raw, ora, bv, gv)
+    assert rel_max_err(A, Ao) < TOL
+    assert np.linalg.norm(b - bo) <= TOL * np.linalg.norm(bo)
+    src = rng.random(nc) * g.cell_volumes
+    x, info = discr.solve(g, data, source=src, rtol=1e-13)
+    xo = spla.spsolve(Ao.tocsc(), bo + src)
+    assert np.linalg.norm(bo + src - Ao @ x) <= 1e-11 * np.linalg.norm(bo + src)
+    if hetero == 1.0:
+        assert np.linalg.norm(x - xo) <= TOL * np.linalg.norm(xo)
+    return discr, data
+
+
+def linear_field_exact(lib, g, tol=1e-11):
+    """Homogeneous anisotropic K, Dirichlet p = a.x: MPFA reproduces it exactly."""
+    nc = g.num_cells
+    K = pa.SecondOrderTensor(kxx=np.ones(nc), kyy=3 * np.ones(nc), kzz=0.3 * np.ones(nc),
+                             kxy=0.4 * np.ones(nc), kxz=0.05 * np.ones(nc) if g.dim == 3 else None,
+                             kyz=0.1 * np.ones(nc) if g.dim == 3 else None)
+    a = np.array([1.0, -2.0, 0.5])
+    bf = g.get_all_boundary_faces()
+    bc = pa.BoundaryCondition(g, bf, ["dir"] * bf.size)
+    bv = np.zeros(g.num_faces)
+    bv[bf] = a[: g.dim] @ g.face_centers[: g.dim, bf]
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": bv})
+    d = pa.Mpfa("flow", library=lib)
+    d.discretize(g, data)
+    x, info = d.solve(g, data, rtol=1e-13)
+    exact = a[: g.dim] @ g.cell_centers[: g.dim]
+    assert info["converged"]
+    assert np.max(np.abs(x - exact)) < tol * max(1.0, np.max(np.abs(exact))), np.max(np.abs(x - exact))
+    # constant pressure -> zero flux on every face: (flux + bound_flux restricted) rows sum to 0
+    mats = data[pa.DISCRETIZATION_MATRICES]["flow"]
+    ones_c = np.ones(nc)
+    ones_f = np.zeros(g.num_faces)
+    ones_f[bf] = 1.0
+    q = mats["flux"] @ ones_c + mats["bound_flux"] @ ones_f
+    assert np.max(np.abs(q)) < 1e-10 * abs(mats["flux"]).max()
+    return info

@@ -1,0 +1,143 @@
+"""CPU suite: the kernel sources compiled as a sequential host emulation (oracle/_build,
+test infrastructure) driven through the same C ABI and checked against the oracle, the
+reference's golden matrices and its known-answer vectors.  Covers the host logic too."""
+import numpy as np
+import pytest
+
+import porepy_amd as pa
+from tests import _parity as P
+from tests._golden import case_names
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return P.emulation_library()
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_golden_case(lib, name):
+    P.check_golden_case(lib, name)
+
+
+def test_generic_pattern_bit_exact(lib):
+    P.check_generic_pattern_bit_exact(lib)
+
+
+@pytest.mark.parametrize("key", ["cart_homogeneous", "cart_heterogeneous",
+                                 "simplex_homogeneous", "simplex_heterogeneous"])
+def test_reference_known_answers(lib, key):
+    P.check_known_answer(lib, key)
+
+
+@pytest.mark.parametrize("make", [
+    lambda: pa.CartGrid([6, 5], [1, 1]),
+    lambda: pa.CartGrid([4, 3, 3], [1, 1, 1]),
+    lambda: pa.perturb_interior_nodes(_geo(pa.CartGrid([5, 5], [1, 1])), 0.05),
+    lambda: pa.perturb_interior_nodes(_geo(pa.StructuredTriangleGrid([5, 4], [1, 1])), 0.05),
+    lambda: pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([3, 3, 2], [1, 1, 1])), 0.06),
+])
+def test_operator_api_on_own_grids(lib, make):
+    g = make()
+    g.compute_geometry()
+    P.operator_roundtrip(lib, g)
+
+
+def _geo(g):
+    g.compute_geometry()
+    return g
+
+
+def test_heterogeneous_1e6(lib):
+    g = _geo(pa.StructuredTetrahedralGrid([3, 3, 3], [1, 1, 1]))
+    P.operator_roundtrip(lib, g, kinds=("dir", "neu"), hetero=1e6)
+    P.operator_roundtrip(lib, g, kinds=("dir", "rob"), hetero=1e-6)
+
+
+@pytest.mark.parametrize("make", [
+    lambda: pa.CartGrid([7, 6], [1, 1]),
+    lambda: pa.CartGrid([4, 4, 4], [1, 1, 1]),
+    lambda: pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([4, 4, 4], [1, 1, 1])), 0.05),
+])
+def test_linear_field_exact(lib, make):
+    g = make()
+    g.compute_geometry()
+    P.linear_field_exact(lib, g)
+
+
+def test_cartesian_laplacian_is_symmetric_and_cg_works(lib):
+    g = _geo(pa.CartGrid([8, 8], [1, 1]))
+    K = pa.SecondOrderTensor(np.ones(g.num_cells))
+    bf = g.get_all_boundary_faces()
+    bc = pa.BoundaryCondition(g, bf, ["dir"] * bf.size)
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc,
+                                           "bc_values": np.zeros(g.num_faces)})
+    d = pa.Mpfa("flow", library=lib)
+    d.discretize(g, data)
+    A, b = d.assemble_matrix_rhs(g, data)
+    assert abs(A - A.T).max() < 1e-13
+    x, info = d.solve(g, data, source=g.cell_volumes, method="cg", rtol=1e-12)
+    assert info["converged"]
+    assert np.linalg.norm(A @ x - g.cell_volumes) < 1e-11 * np.linalg.norm(g.cell_volumes)
+
+
+def test_tutorial_sum_and_config_c1(lib):
+    """tutorials/flux_discretizations.ipynb cell 30 and BASELINE config 1 of the reference."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "scalar_known_answers.npz"))
+    g = _geo(pa.CartGrid([20, 20], [1, 1]))
+    K = pa.SecondOrderTensor(np.ones(g.num_cells))
+    bf = g.get_all_boundary_faces()
+    bc = pa.BoundaryCondition(g, bf, ["dir"] * bf.size)
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc,
+                                           "bc_values": np.zeros(g.num_faces)})
+    d = pa.Mpfa("flow", library=lib)
+    d.discretize(g, data)
+    p, _ = d.solve(g, data, source=g.cell_volumes, rtol=1e-13)
+    assert np.isclose(p.sum(), float(z["tutorial_sum_documented"]))
+    assert abs(p.sum() - float(z["tutorial_sum_reference_today"])) < 1e-10 * p.sum()
+    g = _geo(pa.CartGrid([50, 50], [1, 1]))
+    K = pa.SecondOrderTensor(np.ones(g.num_cells))
+    bf = g.get_all_boundary_faces()
+    west = bf[g.face_centers[0, bf] < 1e-10]
+    east = bf[g.face_centers[0, bf] > 1 - 1e-10]
+    bc = pa.BoundaryCondition(g, np.r_[west, east], ["dir"] * (west.size + east.size))
+    bv = np.zeros(g.num_faces)
+    bv[west], bv[east] = 5.0, 2.0
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": bv})
+    d = pa.Mpfa("flow", library=lib)
+    d.discretize(g, data)
+    p, info = d.solve(g, data, rtol=1e-13)
+    assert abs(p.sum() - float(z["c1_sum_reference_today"])) < 1e-9 * p.sum()
+    assert np.allclose([p.min(), p.max()], z["c1_min_max"])
+
+
+def test_error_behaviour_matches_reference(lib):
+    # singular local system -> ValueError with the reference's message
+    g = _geo(pa.CartGrid([3, 3], [1, 1]))
+    K = pa.SecondOrderTensor(np.zeros(g.num_cells))
+    bf = g.get_all_boundary_faces()
+    bc = pa.BoundaryCondition(g, bf, ["dir"] * bf.size)
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc})
+    with pytest.raises(ValueError, match="Error in inversion of local linear systems"):
+        pa.Mpfa("flow", library=lib).discretize(g, data)
+    # bad call order
+    ctx = pa.Context(0, lib)
+    with pytest.raises(pa.PorefvError):
+        ctx.discretize()
+    # 1-D grids are not part of this path
+    class G1:
+        dim = 1
+    with pytest.raises(NotImplementedError):
+        pa.Mpfa("flow", library=lib)._upload_grid(ctx, G1())
+
+
+def test_rediscretize_with_new_parameters_reuses_topology(lib):
+    g = _geo(pa.StructuredTriangleGrid([4, 4], [1, 1]))
+    d, data = P.operator_roundtrip(lib, g, seed=1)
+    st1 = d.context(g).stats()
+    data[pa.PARAMETERS]["flow"]["second_order_tensor"] = pa.SecondOrderTensor(2 * np.ones(g.num_cells))
+    f_old = data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"].copy()
+    d.discretize(g, data)
+    f_new = data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"]
+    assert abs(f_new - f_old).max() > 1e-3
+    assert d.context(g).stats()["num_sub_half_faces"] == st1["num_sub_half_faces"]
