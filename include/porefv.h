@@ -151,6 +151,10 @@ pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out);
 enum { PFV_KERNEL_SPMV_A = 0, PFV_KERNEL_NODE = 1, PFV_KERNEL_FACE = 2 };
 pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms);
 
+/* Test hook: copy an internal FP64 device array to the host (0 = rows of A^-1 of all nodes,
+ * 1 = rows of the flux operator T, both in node_mptr order; count <= its length). */
+pfv_status pfv_debug_copy(pfv_ctx* h, int which, double* dst, int64_t count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ EXPORTS = [
     "pfv_create", "pfv_destroy", "pfv_last_error", "pfv_is_device_build", "pfv_set_grid",
     "pfv_mpfa_set_params", "pfv_mpfa_discretize", "pfv_matrix_info", "pfv_get_matrix",
     "pfv_mpfa_assemble", "pfv_get_rhs", "pfv_spmv", "pfv_solve", "pfv_spmv_device",
-    "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel",
+    "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
 ]
 
 
@@ -103,6 +103,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_get_stats.restype = C.c_int
     lib.pfv_time_kernel.argtypes = [_h, C.c_int, C.c_int, _dp]
     lib.pfv_time_kernel.restype = C.c_int
+    lib.pfv_debug_copy.argtypes = [_h, C.c_int, _dp, C.c_int64]
+    lib.pfv_debug_copy.restype = C.c_int
     return lib
 
 
@@ -267,6 +269,13 @@ class Context:
 
     def sync(self):
         self._check(self.lib.pfv_sync(self._h))
+
+    def debug_array(self, which: int) -> np.ndarray:
+        """Internal per-node operator rows (0: A^-1, 1: T), for tests."""
+        n = self.stats()["sum_block_sq"]
+        out = np.empty(n, dtype=np.float64)
+        self._check(self.lib.pfv_debug_copy(self._h, int(which), _ptr(out, _dp), n))
+        return out
 
     def time_kernel(self, kernel: int, reps: int = 10) -> float:
         """Average ms per launch (HIP events on the handle's stream); 0 SpMV(A), 1 node, 2 face."""

@@ -27,15 +27,19 @@
 
 #ifdef PFV_EMULATE
 #define PFV_HD
+#define PFV_FN inline
 #define PFV_LAMBDA [=]
-#define PFV_LANES(i, n) for (int i = 0; i < (int)(n); ++i)
 #else
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #define PFV_HD __host__ __device__
+// helpers that take LDS pointers must be inlined into the kernel, otherwise the pointers decay
+// to the flat address space and every LDS access becomes a (slow, vmcnt-coupled) flat_load/store
+#define PFV_FN __host__ __device__ __attribute__((always_inline)) inline
 #define PFV_LAMBDA [=] __device__
-#define PFV_LANES(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += 64)
 #endif
+// lane-strided loop of the wavefront (or lane group) that owns work item `w`
+#define PFV_LANES(i, n) for (int i = w.lane; i < (int)(n); i += w.width)
 
 namespace pfv {
 
@@ -184,14 +188,42 @@ struct Timer {
 
 // ---------------------------------------------------------------- launches
 struct WaveCtx {
-  int64_t item;  // work item this wavefront owns (node, face, cell, ...)
-  char* lds;     // LDS scratch for this wavefront (16-byte aligned)
+  int64_t item;  // work item this lane group owns (node, face, cell, ...)
+  char* lds;     // LDS scratch of this lane group (16-byte aligned)
+  int lane;      // lane index within the group, 0 .. width-1
+  int width;     // lanes per work item: 64 (one wavefront) or a power of two below it
 #ifdef PFV_EMULATE
   bool lane0() const { return true; }
   void sync() const {}
+  // index in [lo, hi) of the largest |base[i * stride]| (lowest index on ties)
+  int argmax_abs(const double* base, int stride, int lo, int hi, double* best) const {
+    double b = -1.0;
+    int p = lo;
+    for (int i = lo; i < hi; ++i) {
+      const double a = std::fabs(base[(size_t)i * stride]);
+      if (a > b) { b = a; p = i; }
+    }
+    *best = b;
+    return p;
+  }
 #else
-  __device__ bool lane0() const { return threadIdx.x == 0; }
+  __device__ bool lane0() const { return lane == 0; }
   __device__ void sync() const { __syncthreads(); }
+  __device__ int argmax_abs(const double* base, int stride, int lo, int hi, double* best) const {
+    double b = -1.0;
+    int p = 0x7fffffff;
+    for (int i = lo + lane; i < hi; i += width) {
+      const double a = fabs(base[(size_t)i * stride]);
+      if (a > b) { b = a; p = i; }
+    }
+    for (int o = width >> 1; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(b, o, width);
+      const int op = __shfl_xor(p, o, width);
+      if (ob > b || (ob == b && op < p)) { b = ob; p = op; }
+    }
+    *best = b;
+    return p;
+  }
 #endif
 };
 
@@ -201,12 +233,19 @@ __global__ void __launch_bounds__(256) k_parallel_for(int64_t n, F f) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) f(i);
 }
-template <class F>
-__global__ void __launch_bounds__(64) k_wave_for(int64_t n, F f) {
+// G lanes per work item, 64 / G items per single-wavefront workgroup.  A workgroup is one
+// wavefront, so __syncthreads() is a scheduling no-op plus the LDS ordering fence we need.
+template <int G, class F>
+__global__ void __launch_bounds__(64) k_wave_for(int64_t n, size_t lds_per_item, F f) {
   extern __shared__ __attribute__((aligned(16))) char pfv_lds[];
-  for (int64_t b = blockIdx.x; b < n; b += gridDim.x) {
-    WaveCtx w{b, pfv_lds};
-    f(w);
+  constexpr int per_block = 64 / G;
+  const int grp = (int)threadIdx.x / G;
+  for (int64_t b0 = (int64_t)blockIdx.x * per_block; b0 < n; b0 += (int64_t)gridDim.x * per_block) {
+    const int64_t b = b0 + grp;
+    if (b < n) {
+      WaveCtx w{b, pfv_lds + (size_t)grp * lds_per_item, (int)threadIdx.x % G, G};
+      f(w);
+    }
     __syncthreads();
   }
 }
@@ -227,8 +266,8 @@ inline void parallel_for(stream_t s, int64_t n, F f) {
 #endif
 }
 
-// One 64-lane wavefront per work item, `lds_bytes` of LDS each.
-template <class F>
+// G lanes (default: one 64-lane wavefront) per work item, `lds_bytes` of LDS per item.
+template <int G = 64, class F>
 inline void wave_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
   if (n <= 0) return;
   lds_bytes = (lds_bytes + 15) & ~size_t(15);
@@ -236,19 +275,22 @@ inline void wave_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
   (void)s;
   std::vector<double> lds((lds_bytes + 7) / 8 + 2);
   for (int64_t b = 0; b < n; ++b) {
-    WaveCtx w{b, reinterpret_cast<char*>(lds.data())};
+    WaveCtx w{b, reinterpret_cast<char*>(lds.data()), 0, 1};
     f(w);
   }
 #else
-  if (lds_bytes > 160 * 1024) throw Error(5, "work item needs more than 160 KiB of LDS");
-  int64_t blocks = n;
+  constexpr int per_block = 64 / G;
+  const size_t block_lds = lds_bytes * per_block;
+  if (block_lds > 160 * 1024) throw Error(5, "work item needs more than 160 KiB of LDS");
+  int64_t blocks = (n + per_block - 1) / per_block;
   // enough resident wavefronts to fill 256 CUs several times over, then grid-stride
   if (blocks > 256 * 64) blocks = 256 * 64;
-  if (lds_bytes > 48 * 1024) {
-    PFV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_for<F>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  if (block_lds > 48 * 1024) {
+    PFV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_for<G, F>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wave_for<F>), dim3((unsigned)blocks), dim3(64), lds_bytes, s, n, f);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wave_for<G, F>), dim3((unsigned)blocks), dim3(64), block_lds, s, n,
+                     lds_bytes, f);
   PFV_HIP_CHECK(hipGetLastError());
 #endif
 }
@@ -311,7 +353,7 @@ inline T read_scalar(stream_t s, const T* dptr) {
 
 // ---------------------------------------------------------------- small device helpers
 template <class T>
-PFV_HD inline int lower_bound_idx(const T* a, int n, T key) {
+PFV_FN int lower_bound_idx(const T* a, int n, T key) {
   int lo = 0, hi = n;
   while (lo < hi) {
     int mid = (lo + hi) >> 1;

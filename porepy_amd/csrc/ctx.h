@@ -12,6 +12,15 @@ constexpr int kMaxBlock = 255;     // local sub-face / sub-cell indices are stor
 static const int kClassBounds[] = {4, 8, 12, 16, 24, 32, 40, 48, 64, 96, 128, 192, 255};
 constexpr int kNumClasses = 13;
 
+// per sub-face (face, node) lookup record used by the face kernel: one 16-byte load replaces the
+// chain face_nodes -> node -> {node_fptr, node_mptr, node_hptr}
+struct SfMeta {
+  int64_t m0row;  // offset of this sub-face's row in the node's n x n blocks (Ainv / Tmat)
+  int32_t h0;     // first sub-half-face of the node
+  uint16_t n;     // sub-faces of the node (row length)
+  uint16_t deg;   // cells of the node
+};
+
 struct CsrPattern {
   int64_t nrows = 0, ncols = 0, nnz = 0;
   Buf<int32_t> indptr, indices;
@@ -59,9 +68,10 @@ struct pfv_ctx_impl {
   Buf<int32_t> node_bfaces;   //   face ids, ascending
   Buf<uint8_t> node_bls;      //   their local subface index
   Buf<int64_t> node_mptr;     // [nn+1] prefix of n(v)^2: offset of the node's n x n blocks
+  Buf<SfMeta> sf_meta;        // [nsf] see SfMeta
   Buf<int32_t> node_order;    // [nn] nodes sorted by block-size class
   std::vector<int64_t> class_begin;  // host: first position of each size class in node_order
-  int max_block = 0, max_deg = 0;
+  int max_block = 0, max_deg = 0, max_face_nodes = 0;
   int64_t sum_block_sq = 0;
 
   // ---- per-node numeric results consumed by the face kernel ---------------------

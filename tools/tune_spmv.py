@@ -1,0 +1,26 @@
+"""GPU tuning helper: time SpMV variants (selected through env hooks read per launch) on the
+bench problem, one process, one grid."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench, porepy_amd as pa
+
+n = int(os.environ.get("TUNE_N", "69"))
+g, K, bc, bv, src = bench.make_problem(n)
+ctx = pa.Context(0); ctx.set_grid(pa.grid_to_raw(g))
+ctx.set_params(K.values, pa.bc_flags(bc), bc.robin_weight, pa.determine_eta(g))
+ctx.discretize(); ctx.assemble(bv, None, src)
+nnz = ctx.matrix_info(6)[2]; nc = g.num_cells
+by = 12.0 * nnz + 4.0 * (nc + 1) + 16.0 * nc
+variants = [("L32", {}), ("L16", {"PFV_SPMV_L": "16"}), ("L8", {"PFV_SPMV_L": "8"}), ("L64", {"PFV_SPMV_L": "64"}),
+            ("L32nt", {"PFV_SPMV_NT": "1"}), ("L16nt", {"PFV_SPMV_L": "16", "PFV_SPMV_NT": "1"}),
+            ("L16nocap", {"PFV_SPMV_L": "16", "PFV_SPMV_BLOCKS": "0"}), ("L32nocap", {"PFV_SPMV_BLOCKS": "0"}),
+            ("L16cap2k", {"PFV_SPMV_L": "16", "PFV_SPMV_BLOCKS": "2048"}),
+            ("L16cap64k", {"PFV_SPMV_L": "16", "PFV_SPMV_BLOCKS": "65536"})]
+for tag, env in variants:
+    for k in ("PFV_SPMV_L", "PFV_SPMV_NT", "PFV_SPMV_BLOCKS"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    ms = min(ctx.time_kernel(0, 30) for _ in range(3))
+    print(f"{tag:10s} {ms*1e3:8.1f} us  {by/ms/1e6:8.1f} GB/s", flush=True)
+print(json.dumps(ctx.stats()))
