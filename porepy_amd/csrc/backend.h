@@ -362,6 +362,34 @@ PFV_FN int lower_bound_idx(const T* a, int n, T key) {
   return lo;
 }
 
+template <class T>
+PFV_FN int upper_bound_idx(const T* a, int n, T key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] <= key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+PFV_HD inline int popcount64(unsigned long long x) { return __builtin_popcountll(x); }
+PFV_HD inline void atomic_or_u64(unsigned long long* addr, unsigned long long v) {
+#ifdef PFV_EMULATE
+  *addr |= v;
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicOr(addr, v);
+#else
+  (void)addr; (void)v;
+#endif
+#endif
+}
+
+// running maximum kept by one lane per work item: same-address atomics serialise at ~11 ns
+// each (4 M items = 45 ms), so only touch the word when the value can raise it
+PFV_HD inline void atomic_max_i32(int* addr, int v);
+PFV_HD inline void track_max_i32(int* addr, int v) {
+  if (v > *reinterpret_cast<volatile int*>(addr)) atomic_max_i32(addr, v);
+}
 PFV_HD inline void atomic_max_i32(int* addr, int v) {
 #ifdef PFV_EMULATE
   if (v > *addr) *addr = v;

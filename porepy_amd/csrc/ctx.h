@@ -71,7 +71,7 @@ struct pfv_ctx_impl {
   Buf<SfMeta> sf_meta;        // [nsf] see SfMeta
   Buf<int32_t> node_order;    // [nn] nodes sorted by block-size class
   std::vector<int64_t> class_begin;  // host: first position of each size class in node_order
-  int max_block = 0, max_deg = 0, max_face_nodes = 0;
+  int max_block = 0, max_deg = 0, max_face_nodes = 0, max_cell_faces = 0;
   int64_t sum_block_sq = 0;
 
   // ---- per-node numeric results consumed by the face kernel ---------------------

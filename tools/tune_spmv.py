@@ -12,13 +12,14 @@ ctx.set_params(K.values, pa.bc_flags(bc), bc.robin_weight, pa.determine_eta(g))
 ctx.discretize(); ctx.assemble(bv, None, src)
 nnz = ctx.matrix_info(6)[2]; nc = g.num_cells
 by = 12.0 * nnz + 4.0 * (nc + 1) + 16.0 * nc
-variants = [("L32", {}), ("L16", {"PFV_SPMV_L": "16"}), ("L8", {"PFV_SPMV_L": "8"}), ("L64", {"PFV_SPMV_L": "64"}),
-            ("L32nt", {"PFV_SPMV_NT": "1"}), ("L16nt", {"PFV_SPMV_L": "16", "PFV_SPMV_NT": "1"}),
-            ("L16nocap", {"PFV_SPMV_L": "16", "PFV_SPMV_BLOCKS": "0"}), ("L32nocap", {"PFV_SPMV_BLOCKS": "0"}),
-            ("L16cap2k", {"PFV_SPMV_L": "16", "PFV_SPMV_BLOCKS": "2048"}),
-            ("L16cap64k", {"PFV_SPMV_L": "16", "PFV_SPMV_BLOCKS": "65536"})]
+variants = [("L16U1", {"PFV_SPMV_L": "16", "PFV_SPMV_U": "1"}), ("L16U2", {"PFV_SPMV_L": "16", "PFV_SPMV_U": "2"}),
+            ("L16U3", {"PFV_SPMV_L": "16", "PFV_SPMV_U": "3"}), ("L16U4", {"PFV_SPMV_L": "16", "PFV_SPMV_U": "4"}),
+            ("L16U5", {"PFV_SPMV_L": "16", "PFV_SPMV_U": "5"}), ("L8U4", {"PFV_SPMV_L": "8", "PFV_SPMV_U": "4"}),
+            ("L8U5", {"PFV_SPMV_L": "8", "PFV_SPMV_U": "5"}), ("L32U3", {"PFV_SPMV_L": "32", "PFV_SPMV_U": "3"}),
+            ("L4U5", {"PFV_SPMV_L": "4", "PFV_SPMV_U": "5"}), ("L16U5nt", {"PFV_SPMV_L": "16", "PFV_SPMV_U": "5", "PFV_SPMV_NT": "1"}),
+            ("default", {})]
 for tag, env in variants:
-    for k in ("PFV_SPMV_L", "PFV_SPMV_NT", "PFV_SPMV_BLOCKS"):
+    for k in ("PFV_SPMV_L", "PFV_SPMV_NT", "PFV_SPMV_BLOCKS", "PFV_SPMV_U"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ms = min(ctx.time_kernel(0, 30) for _ in range(3))
