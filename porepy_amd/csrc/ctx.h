@@ -69,6 +69,10 @@ struct pfv_ctx_impl {
   Buf<uint8_t> node_bls;      //   their local subface index
   Buf<int64_t> node_mptr;     // [nn+1] prefix of n(v)^2: offset of the node's n x n blocks
   Buf<SfMeta> sf_meta;        // [nsf] see SfMeta
+  Buf<uint8_t> flux_colpairs; // [nnz(flux) * max_face_nodes] for every flux column: the (node of face, cell) pair per node, 0xff = none
+  Buf<int32_t> face_order;    // [nf] faces along a Morton curve of their centres: processing order of the
+                              //      face kernels, so that faces sharing nodes run close in time (L2 reuse)
+  double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {1, 1, 1};
   Buf<int32_t> node_order;    // [nn] nodes sorted by block-size class
   std::vector<int64_t> class_begin;  // host: first position of each size class in node_order
   int max_block = 0, max_deg = 0, max_face_nodes = 0, max_cell_faces = 0;

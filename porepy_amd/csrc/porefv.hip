@@ -122,6 +122,16 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     h->ncf = cf_indptr[nc];
     h->nsf = fn_indptr[nf];
     require(cf_indptr[0] == 0 && fn_indptr[0] == 0, "indptr must start at 0");
+    for (int d = 0; d < 3; ++d) {
+      double lo = face_centers[(size_t)d * nf], hi = lo;
+      for (int64_t f = 1; f < nf; ++f) {
+        const double x = face_centers[(size_t)d * nf + f];
+        lo = x < lo ? x : lo;
+        hi = x > hi ? x : hi;
+      }
+      h->bbox_lo[d] = lo;
+      h->bbox_hi[d] = hi;
+    }
     upload(h->nodes, nodes, 3 * (size_t)nn, s);
     upload(h->fnorm, face_normals, 3 * (size_t)nf, s);
     upload(h->fcen, face_centers, 3 * (size_t)nf, s);
