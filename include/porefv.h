@@ -140,7 +140,17 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
 /* Device-pointer variants for multi-GPU drivers that keep vectors in HBM
  * (torch tensors): y = A x on the handle's stream; d_x has num_cols entries. */
 pfv_status pfv_spmv_device(pfv_ctx* h, int which, const double* d_x, double* d_y);
+/* same, but only rows [0, nrows): a sharded solve multiplies the rows of the cells a rank owns
+ * (owned cells are numbered first) against owned + halo entries of x */
+pfv_status pfv_spmv_device_rows(pfv_ctx* h, int which, int64_t nrows, const double* d_x, double* d_y);
 pfv_status pfv_get_device_rhs(pfv_ctx* h, double** d_b, double** d_diag);
+/* device-to-device copy of an internal vector into caller memory (e.g. a torch tensor):
+ * which = 0 right-hand side b (Nc), 1 diagonal of A (Nc) */
+pfv_status pfv_copy_device_vector(pfv_ctx* h, int which, double* d_dst, int64_t count);
+/* run this handle's work on an externally owned HIP stream (hipStream_t passed as void*, e.g.
+ * torch.cuda.current_stream().cuda_stream) so that it is ordered with the caller's kernels and
+ * RCCL collectives; NULL restores the handle's own stream */
+pfv_status pfv_set_stream(pfv_ctx* h, void* hip_stream);
 pfv_status pfv_sync(pfv_ctx* h);
 
 pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out);

@@ -31,6 +31,7 @@ EXPORTS = [
     "pfv_mpfa_set_params", "pfv_mpfa_discretize", "pfv_matrix_info", "pfv_get_matrix",
     "pfv_mpfa_assemble", "pfv_get_rhs", "pfv_spmv", "pfv_solve", "pfv_spmv_device",
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
+    "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
 ]
 
 
@@ -105,6 +106,12 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_time_kernel.restype = C.c_int
     lib.pfv_debug_copy.argtypes = [_h, C.c_int, _dp, C.c_int64]
     lib.pfv_debug_copy.restype = C.c_int
+    lib.pfv_spmv_device_rows.argtypes = [_h, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.pfv_spmv_device_rows.restype = C.c_int
+    lib.pfv_copy_device_vector.argtypes = [_h, C.c_int, C.c_void_p, C.c_int64]
+    lib.pfv_copy_device_vector.restype = C.c_int
+    lib.pfv_set_stream.argtypes = [_h, C.c_void_p]
+    lib.pfv_set_stream.restype = C.c_int
     return lib
 
 
@@ -269,6 +276,16 @@ class Context:
 
     def sync(self):
         self._check(self.lib.pfv_sync(self._h))
+
+    # ---- device-pointer entry points (vectors owned by the caller, e.g. torch tensors) ----
+    def spmv_device_rows(self, which: int, nrows: int, x_ptr: int, y_ptr: int):
+        self._check(self.lib.pfv_spmv_device_rows(self._h, which, int(nrows), C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+
+    def copy_device_vector(self, which: int, dst_ptr: int, count: int):
+        self._check(self.lib.pfv_copy_device_vector(self._h, which, C.c_void_p(dst_ptr), int(count)))
+
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self.lib.pfv_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
 
     def debug_array(self, which: int) -> np.ndarray:
         """Internal per-node operator rows (0: A^-1, 1: T), for tests."""

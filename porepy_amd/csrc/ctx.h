@@ -29,7 +29,8 @@ struct CsrPattern {
 
 struct pfv_ctx_impl {
   int device = 0;
-  stream_t stream{};
+  stream_t stream{};      // stream all work of this handle is issued on
+  stream_t own_stream{};  // the stream created with the handle (stream may point elsewhere, pfv_set_stream)
   std::string err;
   Scratch scratch;
 

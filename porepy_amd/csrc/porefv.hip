@@ -76,6 +76,7 @@ pfv_status pfv_create(int device, pfv_ctx** out) {
     }
     PFV_HIP_CHECK(hipSetDevice(device));
     PFV_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = h->stream;
 #endif
   } catch (...) {
     delete h;
@@ -92,7 +93,7 @@ void pfv_destroy(pfv_ctx* h) {
   if (h->stream) {
     (void)hipStreamSynchronize(h->stream);
   }
-  hipStream_t s = h->stream;
+  hipStream_t s = h->own_stream;
   delete h;
   if (s) (void)hipStreamDestroy(s);
 #else
@@ -277,6 +278,49 @@ pfv_status pfv_spmv_device(pfv_ctx* h, int which, const double* d_x, double* d_y
     require(which >= 0 && which < PFV_NUM_MATS && d_x && d_y, "bad argument");
     require(h->have_symbolic && h->filled[which], "matrix values have not been computed");
     pfv::spmv(*h, h->pattern_of(which), h->val[which], d_x, d_y);
+  });
+}
+
+pfv_status pfv_spmv_device_rows(pfv_ctx* h, int which, int64_t nrows, const double* d_x, double* d_y) {
+  return guarded(h, [&] {
+    require(which >= 0 && which < PFV_NUM_MATS && d_x && d_y, "bad argument");
+    require(h->have_symbolic && h->filled[which], "matrix values have not been computed");
+    const pfv::CsrPattern& P = h->pattern_of(which);
+    require(nrows >= 0 && nrows <= P.nrows, "nrows out of range");
+    pfv::CsrPattern V;  // view of the leading rows (shares the index arrays)
+    V.nrows = nrows;
+    V.ncols = P.ncols;
+    V.nnz = P.nrows ? (int64_t)((double)P.nnz * (double)nrows / (double)P.nrows) : 0;
+    V.indptr.p = P.indptr.p;
+    V.indices.p = P.indices.p;
+    try {
+      pfv::spmv(*h, V, h->val[which], d_x, d_y);
+    } catch (...) {
+      V.indptr.p = nullptr;
+      V.indices.p = nullptr;
+      throw;
+    }
+    V.indptr.p = nullptr;  // not owned
+    V.indices.p = nullptr;
+  });
+}
+
+pfv_status pfv_copy_device_vector(pfv_ctx* h, int which, double* d_dst, int64_t count) {
+  return guarded(h, [&] {
+    require(h->have_system && d_dst && count >= 0 && count <= h->nc, "bad argument / assemble first");
+    require(which == 0 || which == 1, "which must be 0 (rhs) or 1 (diagonal)");
+    pfv::be_d2d(d_dst, which == 0 ? h->rhs.p : h->diag.p, sizeof(double) * (size_t)count, h->stream);
+  });
+}
+
+pfv_status pfv_set_stream(pfv_ctx* h, void* hip_stream) {
+  return guarded(h, [&] {
+#ifdef PFV_EMULATE
+    (void)hip_stream;
+#else
+    pfv::be_sync(h->stream);
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+#endif
   });
 }
 

@@ -1,0 +1,169 @@
+"""World-size-2 run of the sharded assembly + solve on CPU: `gloo` process group, the host
+emulation build of the kernels behind the same C ABI.  Checks that (i) the rows of A owned by
+a rank equal the rows of the single-domain matrix bit for bit in pattern and to 1e-12 in value
+(assembly needs no communication), (ii) the halo-exchanging BiCGStab / CG reproduce the
+single-domain solution."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+import porepy_amd as pa
+from porepy_amd import distributed as D
+from tests import _parity as P
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem(kind):
+    if kind == "tet":
+        g = pa.StructuredTetrahedralGrid([4, 4, 6], [1, 1, 1.5])
+        g.compute_geometry()
+        g = pa.perturb_interior_nodes(g, 0.04, seed=3)
+    else:
+        g = pa.CartGrid([6, 5, 8], [1, 1, 1])
+        g.compute_geometry()
+    nc = g.num_cells
+    rng = np.random.default_rng(5)
+    if kind == "tet":
+        K = pa.SecondOrderTensor(kxx=1 + rng.random(nc), kyy=3 + rng.random(nc), kzz=0.5 + rng.random(nc),
+                                 kxy=0.3 * rng.random(nc), kxz=0.1 * rng.random(nc), kyz=0.1 * rng.random(nc))
+    else:
+        K = pa.SecondOrderTensor(1 + rng.random(nc))
+    bf = g.get_all_boundary_faces()
+    dirf = bf[(g.face_centers[0, bf] < 1e-9) | (g.face_centers[0, bf] > 1 - 1e-9)]
+    bc = pa.BoundaryCondition(g, dirf, ["dir"] * dirf.size)
+    bv = np.zeros(g.num_faces)
+    bv[dirf] = 1 + g.face_centers[1, dirf]
+    src = g.cell_volumes * (1 + rng.random(nc))
+    return g, K, bc, bv, src
+
+
+def _worker(rank, world, port, kind, method, out):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = P.emulation_library()
+        g, K, bc, bv, src = _problem(kind)
+        raw = pa.grid_to_raw(g)
+        owner = D.partition_slabs(raw["cell_centers"], world, axis=2)
+        lp = D.extract_subdomain(raw, owner, rank)
+        sh = D.ShardedMpfa(lp, device="cpu", library=lib, dist=dist)
+        flags = sh.local_bc_flags(pa.bc_flags(bc)[lp.face_gid])
+        sh.discretize(K.values[:, :, lp.cell_gid], flags, bc.robin_weight[lp.face_gid], pa.determine_eta(g))
+        sh.assemble(bv[lp.face_gid], src[lp.cell_gid])
+        A_own, b_own = sh.owned_system_rows()
+        x, info = sh.solve(method=method, rtol=1e-12, maxit=3000, check_every=1)
+        torch.save({"gid": lp.cell_gid, "n_own": lp.n_own, "A": A_own, "b": b_own, "x": x.numpy(),
+                    "info": info}, os.path.join(out, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,method", [("tet", "bicgstab"), ("cart", "cg")])
+def test_two_rank_sharded_assembly_and_solve(tmp_path, kind, method):
+    import torch
+    import torch.multiprocessing as mp
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, method, str(tmp_path)), nprocs=world, join=True)
+    # single-domain reference through the same library
+    lib = P.emulation_library()
+    g, K, bc, bv, src = _problem(kind)
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": bv})
+    d = pa.Mpfa("flow", library=lib)
+    d.discretize(g, data)
+    A, b = d.assemble_matrix_rhs(g, data)
+    x_ref = spla.spsolve(A.tocsc(), b + src)
+    seen = np.zeros(g.num_cells, dtype=bool)
+    for r in range(world):
+        o = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"), weights_only=False)
+        gid, n_own = o["gid"], o["n_own"]
+        own = gid[:n_own]
+        assert not seen[own].any()
+        seen[own] = True
+        # rows of owned cells: same pattern (after mapping local columns to global ids), same values
+        Aloc = o["A"].tocoo()
+        Aglob = A[own].tocoo()
+        loc = sorted(zip(Aloc.row.tolist(), gid[Aloc.col].tolist()))
+        glo = sorted(zip(Aglob.row.tolist(), Aglob.col.tolist()))
+        assert loc == glo
+        M = A[own][:, gid]  # global rows restricted to the local column set, in local numbering
+        assert abs(M - o["A"]).max() <= 1e-12 * abs(A).max()
+        assert np.allclose(o["b"], (b + src)[own], rtol=1e-12, atol=1e-14)
+        assert o["info"]["converged"]
+        assert np.linalg.norm(o["x"] - x_ref[own]) <= 1e-9 * np.linalg.norm(x_ref)
+    assert seen.all()
+
+
+def test_halo_plan_single_rank_is_noop():
+    g, K, bc, bv, src = _problem("cart")
+    raw = pa.grid_to_raw(g)
+    lp = D.extract_subdomain(raw, np.zeros(g.num_cells, dtype=np.int32), 0)
+    assert lp.n_own == g.num_cells and lp.halo_owner.size == 0
+    plan = D.HaloPlan(lp, None)
+    assert plan.bytes_per_exchange == 0
+
+
+def _slab_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = P.emulation_library()
+        lp, Kv, flags, bv, src, eta = bench.make_slab_problem(4, rank, world, layers=3)
+        sh = D.ShardedMpfa(lp, device="cpu", library=lib, dist=dist)
+        sh.discretize(Kv, flags, None, eta)
+        sh.assemble(bv, src)
+        x, info = sh.solve("bicgstab", rtol=1e-12, maxit=3000, check_every=1)
+        torch.save({"gid": lp.cell_gid[: lp.n_own], "x": x.numpy(), "info": info}, os.path.join(out, f"s{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_slab_decomposition_matches_single_domain(tmp_path):
+    """The slab problems bench.py builds per rank (no global grid) are one global problem:
+    3 ranks x 3 lattice layers reproduce the 9-layer single-domain solution."""
+    import torch
+    import torch.multiprocessing as mp
+
+    import bench
+
+    world = 3
+    mp.spawn(_slab_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    lib = P.emulation_library()
+    lp, Kv, flags, bv, src, eta = bench.make_slab_problem(4, 0, 1, layers=3 * world)
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(lp.raw)
+    ctx.set_params(Kv, flags, None, eta)
+    ctx.discretize(skip_vector_source=True)
+    ctx.assemble(bv, None, src)
+    A, b = ctx.matrix(6), ctx.rhs()
+    x_ref = np.empty(lp.n_own)
+    x_ref[:] = spla.spsolve(A.tocsc(), b)
+    ref_by_gid = dict(zip(lp.cell_gid.tolist(), x_ref.tolist()))
+    total = 0
+    for r in range(world):
+        o = torch.load(os.path.join(str(tmp_path), f"s{r}.pt"), weights_only=False)
+        assert o["info"]["converged"]
+        want = np.array([ref_by_gid[g] for g in o["gid"].tolist()])
+        assert np.linalg.norm(o["x"] - want) <= 1e-9 * np.linalg.norm(x_ref)
+        total += o["gid"].size
+    assert total == lp.n_own
