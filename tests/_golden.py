@@ -20,7 +20,43 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers"]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith("mpsa_")]
+
+
+def mpsa_case_names():
+    names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "mpsa_*.npz")))]
+    return names
+
+
+MPSA_KEYS = ("stress", "bound_stress", "bound_displacement_cell", "bound_displacement_face")
+
+
+class MpsaCase:
+    """MPSA fixture made by oracle/gen_golden_mpsa.py from the reference."""
+
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.grid["name"] = str(self.grid["name"])
+        self.bc = {"is_dir": z["bc_is_dir"], "is_neu": z["bc_is_neu"]}
+        self.stiffness = z["stiffness"]
+        self.bc_values = z["bc_values"]
+        self.source = z["source"]
+        eta = float(z["eta"])
+        self.eta = None if np.isnan(eta) else eta
+        self.ref = {}
+        for k in MPSA_KEYS + ("A",):
+            if f"ref_{k}_indptr" in z.files:
+                shape = tuple(int(v) for v in z[f"ref_{k}_shape"])
+                self.ref[k] = sps.csr_matrix(
+                    (z[f"ref_{k}_data"], z[f"ref_{k}_indices"], z[f"ref_{k}_indptr"]), shape=shape)
+        self.ref_rhs = z["ref_rhs"]
+        self.ref_x = z["ref_x"]
+        self.known_u = z["known_u"] if "known_u" in z.files else None
+        self.known_stress = z["known_stress"] if "known_stress" in z.files else None
+        self.known_rhs = z["known_rhs"] if "known_rhs" in z.files else None
 
 
 class Case:

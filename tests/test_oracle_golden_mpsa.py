@@ -1,0 +1,79 @@
+"""Pin the MPSA CPU oracle to the reference (golden fixtures incl. its known-answer vectors)."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from oracle import mpsa_oracle as so
+from tests._golden import MPSA_KEYS, MpsaCase, check_pattern, mpsa_case_names, rel_max_err
+
+TOL = 1e-10
+
+
+@pytest.mark.parametrize("name", mpsa_case_names())
+def test_mpsa_oracle_matches_reference(name):
+    c = MpsaCase(name)
+    out = so.discretize(c.grid, c.stiffness, c.bc, eta=c.eta)
+    for k in MPSA_KEYS:
+        if k not in c.ref:
+            continue
+        assert out[k].shape == c.ref[k].shape
+        assert rel_max_err(out[k], c.ref[k]) < TOL, (name, k)
+        subset, outside, _ = check_pattern(out[k], c.ref[k])
+        assert subset and outside < 1e-12, (name, k, outside)
+    A, b = so.assemble_matrix_rhs(c.grid, out, c.bc_values, c.source)
+    assert rel_max_err(A, c.ref["A"]) < TOL
+    assert np.linalg.norm(b - c.ref_rhs) <= TOL * max(np.linalg.norm(c.ref_rhs), 1e-300)
+    if "hetero" not in name:
+        x = spla.spsolve(A.tocsc(), b)
+        assert np.linalg.norm(x - c.ref_x) <= 1e-9 * np.linalg.norm(c.ref_x)
+
+
+@pytest.mark.parametrize("key", ["cart_homogeneous", "cart_heterogeneous",
+                                 "simplex_homogeneous", "simplex_heterogeneous"])
+def test_mpsa_reference_known_answer_vectors(key):
+    """tests/numerics/fv/test_mpsa.py:1296-1323 of the reference (np.allclose defaults)."""
+    c = MpsaCase("mpsa_known_" + key)
+    out = so.discretize(c.grid, c.stiffness, c.bc, eta=0.0)
+    A, b = so.assemble_matrix_rhs(c.grid, out, c.bc_values)
+    u = spla.spsolve(A.tocsc(), b + c.known_rhs)
+    stress = out["stress"] @ u + out["bound_stress"] @ c.bc_values
+    assert np.allclose(u, c.known_u)
+    assert np.allclose(stress, c.known_stress)
+
+
+def test_uniaxial_compression_is_exact():
+    """BASELINE C4 recipe: mu = lambda = 1, rollers on west/south/bottom, unit
+    traction on top: u = (nu x / E, nu y / E, -z / E) with E = 2.5, nu = 0.25."""
+    import porepy_amd as pa
+
+    g = pa.StructuredTetrahedralGrid([3, 3, 3], [1, 1, 1])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.05)
+    raw = pa.grid_to_raw(g)
+    nc, nf = g.num_cells, g.num_faces
+    C = np.zeros((9, 9, nc))
+    mu = lam = 1.0
+    for i in range(3):
+        for j in range(3):
+            C[3 * i + i, 3 * j + j] += lam
+            C[3 * i + j, 3 * i + j] += mu
+            C[3 * i + j, 3 * j + i] += mu
+    bf = g.get_all_boundary_faces()
+    fc = g.face_centers
+    is_dir = np.zeros((3, nf), bool)
+    is_neu = np.zeros((3, nf), bool)
+    is_neu[:, bf] = True
+    for axis in range(3):
+        roll = bf[fc[axis, bf] < 1e-9]
+        is_dir[axis, roll] = True
+        is_neu[axis, roll] = False
+    bv = np.zeros((3, nf))
+    top = bf[fc[2, bf] > 1 - 1e-9]
+    bv[2, top] = -1.0 * g.face_areas[top]
+    out = so.discretize(raw, C, {"is_dir": is_dir, "is_neu": is_neu})
+    A, b = so.assemble_matrix_rhs(raw, out, bv.ravel("F"))
+    u = spla.spsolve(A.tocsc(), b).reshape(3, -1, order="F")
+    cc = g.cell_centers
+    E, nu = 2.5, 0.25
+    exact = np.vstack((nu * cc[0] / E, nu * cc[1] / E, -cc[2] / E))
+    assert np.max(np.abs(u - exact)) < 1e-12
