@@ -46,7 +46,14 @@ enum {
   PFV_MAT_VECTOR_SOURCE = 4,
   PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE = 5,
   PFV_MAT_SYSTEM = 6,
-  PFV_NUM_MATS = 7
+  /* MPSA: the four keys Mpsa stores (numerics/fv/mpsa.py:82-95) and A = div_nd @ stress
+   * (mpsa.py:515-529); vector unknowns are cell-major, component-minor (u[nd*c + a]) */
+  PFV_MAT_STRESS = 7,
+  PFV_MAT_BOUND_STRESS = 8,
+  PFV_MAT_BOUND_DISPLACEMENT_CELL = 9,
+  PFV_MAT_BOUND_DISPLACEMENT_FACE = 10,
+  PFV_MAT_MECH_SYSTEM = 11,
+  PFV_NUM_MATS = 12
 };
 
 /* boundary-condition flag bits per face (params/bc.py:68-190: is_dir/is_neu/is_rob/
@@ -136,6 +143,22 @@ pfv_status pfv_spmv(pfv_ctx* h, int which, const double* x, double* y);
  * x0 may be NULL (zero start); x receives Nc values. */
 pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart,
                      const double* x0, double* x, pfv_solve_info* info);
+
+/* ---- MPSA-W (numerics/fv/mpsa.py): same grid, vector unknowns ------------------------------
+ * stiffness: FourthOrderTensor.values, shape (9,9,Nc) C-order (params/tensor.py:300-349);
+ * bc_dir_bits / bc_neu_bits: per face, bit a set if component a is Dirichlet / Neumann
+ * (BoundaryConditionVectorial.is_dir / is_neu, params/bc.py:222-322; Cartesian basis, no Robin);
+ * cell_volumes: Grid.cell_volumes (Nc), the weights of the node average (mpsa.py:1619-1640);
+ * eta as in pfv_mpfa_set_params (scalar). */
+pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const double* cell_volumes,
+                               const uint8_t* bc_dir_bits, const uint8_t* bc_neu_bits, double eta);
+/* Mpsa._stress_discretization (numerics/fv/mpsa.py:531-782) on the device; fills matrices 7-10 */
+pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags);
+/* Mpsa.assemble_matrix_rhs (mpsa.py:486-529): A = div_nd @ stress,
+ * b = -div_nd @ bound_stress @ bc_values + source; bc_values has nd*Nf entries ((nd,Nf) raveled
+ * column-major), source nd*Nc or NULL.  Makes the mechanics system the one pfv_solve works on
+ * (pfv_mpfa_assemble switches back to the flow system). */
+pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* source);
 
 /* Device-pointer variants for multi-GPU drivers that keep vectors in HBM
  * (torch tensors): y = A x on the handle's stream; d_x has num_cols entries. */

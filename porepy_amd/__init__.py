@@ -10,12 +10,14 @@ from ._lib import Context, PorefvError
 from .grid import (CartGrid, Grid, StructuredTetrahedralGrid, StructuredTriangleGrid, grid_to_raw,
                    perturb_interior_nodes)
 from .mpfa import Mpfa, as_porepy_discretization, determine_eta
-from .params import (DISCRETIZATION_MATRICES, PARAMETERS, BoundaryCondition, SecondOrderTensor,
-                     bc_flags, bc_to_raw, initialize_data)
+from .mpsa import Mpsa
+from .params import (DISCRETIZATION_MATRICES, PARAMETERS, BoundaryCondition, BoundaryConditionVectorial,
+                     FourthOrderTensor, SecondOrderTensor, bc_flags, bc_to_raw, initialize_data)
 
 __all__ = [
     "Context", "PorefvError", "Grid", "CartGrid", "StructuredTriangleGrid",
     "StructuredTetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "Mpfa",
-    "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition",
+    "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition", "Mpsa",
+    "FourthOrderTensor", "BoundaryConditionVectorial",
     "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib",
 ]

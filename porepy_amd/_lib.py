@@ -17,6 +17,7 @@ DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "libporefv_hip.so")
 
 MAT_FLUX, MAT_BOUND_FLUX, MAT_BOUND_PRESSURE_CELL, MAT_BOUND_PRESSURE_FACE = 0, 1, 2, 3
 MAT_VECTOR_SOURCE, MAT_BOUND_PRESSURE_VECTOR_SOURCE, MAT_SYSTEM = 4, 5, 6
+MAT_STRESS, MAT_BOUND_STRESS, MAT_BOUND_DISPLACEMENT_CELL, MAT_BOUND_DISPLACEMENT_FACE, MAT_MECH_SYSTEM = 7, 8, 9, 10, 11
 BC_DIR, BC_NEU, BC_ROB, BC_INTERNAL = 1, 2, 4, 8
 SOLVE_CG, SOLVE_BICGSTAB, SOLVE_GMRES = 0, 1, 2
 DISCR_REBUILD_TOPOLOGY, DISCR_SKIP_VECTOR_SOURCE = 1, 2
@@ -32,6 +33,7 @@ EXPORTS = [
     "pfv_mpfa_assemble", "pfv_get_rhs", "pfv_spmv", "pfv_solve", "pfv_spmv_device",
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
+    "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
 ]
 
 
@@ -112,6 +114,12 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_copy_device_vector.restype = C.c_int
     lib.pfv_set_stream.argtypes = [_h, C.c_void_p]
     lib.pfv_set_stream.restype = C.c_int
+    lib.pfv_mpsa_set_params.argtypes = [_h, _dp, _dp, _up, _up, C.c_double]
+    lib.pfv_mpsa_set_params.restype = C.c_int
+    lib.pfv_mpsa_discretize.argtypes = [_h, C.c_uint32]
+    lib.pfv_mpsa_discretize.restype = C.c_int
+    lib.pfv_mpsa_assemble.argtypes = [_h, _dp, _dp]
+    lib.pfv_mpsa_assemble.restype = C.c_int
     return lib
 
 
@@ -211,6 +219,36 @@ class Context:
         self._check(self.lib.pfv_mpfa_set_params(self._h, _ptr(perm, _dp), _ptr(flags, _up),
                                                  _ptr(rw, _dp), float(eta), _ptr(es, _dp)))
 
+    # ---- MPSA ----------------------------------------------------------------------
+    def mpsa_set_params(self, stiffness, cell_volumes, is_dir, is_neu, eta=0.0):
+        C9 = _f64(stiffness)
+        if C9.shape != (9, 9, self.nc):
+            raise ValueError(f"stiffness must have shape (9, 9, {self.nc})")
+        vol = _f64(cell_volumes)
+        is_dir, is_neu = np.asarray(is_dir, bool), np.asarray(is_neu, bool)
+        if is_dir.shape != (self.nd, self.nf) or is_neu.shape != (self.nd, self.nf):
+            raise AttributeError("MPSA needs a vectorial boundary condition: is_dir / is_neu of shape (nd, Nf)")
+        wts = (1 << np.arange(self.nd))[:, None]
+        dbits = np.ascontiguousarray((is_dir * wts).sum(axis=0), dtype=np.uint8)
+        nbits = np.ascontiguousarray((is_neu * wts).sum(axis=0), dtype=np.uint8)
+        self._check(self.lib.pfv_mpsa_set_params(self._h, _ptr(C9, _dp), _ptr(vol, _dp), _ptr(dbits, _up),
+                                                 _ptr(nbits, _up), float(eta)))
+
+    def mpsa_discretize(self, rebuild_topology=False):
+        self._check(self.lib.pfv_mpsa_discretize(self._h, DISCR_REBUILD_TOPOLOGY if rebuild_topology else 0))
+
+    def mpsa_assemble(self, bc_values, source=None):
+        bcv = _f64(bc_values)
+        if bcv.shape != (self.nf * self.nd,):
+            raise ValueError("bc_values must have nd * Nf entries")
+        src = None if source is None else _f64(source)
+        self._check(self.lib.pfv_mpsa_assemble(self._h, _ptr(bcv, _dp), _ptr(src, _dp)))
+
+    def active_rhs(self, n):
+        b = np.empty(n, dtype=np.float64)
+        self._check(self.lib.pfv_get_rhs(self._h, _ptr(b, _dp)))
+        return b
+
     # ---- hot path -----------------------------------------------------------------
     def discretize(self, rebuild_topology=False, skip_vector_source=False):
         flags = (DISCR_REBUILD_TOPOLOGY if rebuild_topology else 0) | \
@@ -256,9 +294,10 @@ class Context:
         self._check(self.lib.pfv_spmv(self._h, which, _ptr(x, _dp), _ptr(y, _dp)))
         return y
 
-    def solve(self, method="bicgstab", rtol=1e-12, maxit=10000, x0=None, raise_on_fail=True):
+    def solve(self, method="bicgstab", rtol=1e-12, maxit=10000, x0=None, raise_on_fail=True, n=None):
+        """Solve the system assembled last (flow: n = Nc; mechanics: pass n = nd * Nc)."""
         code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB}[method]
-        x = np.empty(self.nc, dtype=np.float64)
+        x = np.empty(self.nc if n is None else int(n), dtype=np.float64)
         x0a = None if x0 is None else _f64(x0)
         info = SolveInfo()
         st = self.lib.pfv_solve(self._h, code, float(rtol), int(maxit), 0, _ptr(x0a, _dp), _ptr(x, _dp),

@@ -191,7 +191,9 @@ struct WaveCtx {
   int64_t item;  // work item this lane group owns (node, face, cell, ...)
   char* lds;     // LDS scratch of this lane group (16-byte aligned)
   int lane;      // lane index within the group, 0 .. width-1
-  int width;     // lanes per work item: 64 (one wavefront) or a power of two below it
+  int width;     // lanes per work item: 64 (one wavefront), a power of two below it, or a
+                 // multi-wavefront workgroup (block_for)
+  char* red;     // 128 bytes of LDS scratch for cross-wavefront reductions (block_for only)
 #ifdef PFV_EMULATE
   bool lane0() const { return true; }
   void sync() const {}
@@ -216,10 +218,24 @@ struct WaveCtx {
       const double a = fabs(base[(size_t)i * stride]);
       if (a > b) { b = a; p = i; }
     }
-    for (int o = width >> 1; o > 0; o >>= 1) {
-      const double ob = __shfl_xor(b, o, width);
-      const int op = __shfl_xor(p, o, width);
+    const int w = width < 64 ? width : 64;
+    for (int o = w >> 1; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(b, o, w);
+      const int op = __shfl_xor(p, o, w);
       if (ob > b || (ob == b && op < p)) { b = ob; p = op; }
+    }
+    if (width > 64) {  // combine the wavefronts of the workgroup through LDS
+      double* rb = reinterpret_cast<double*>(red);
+      int* rp = reinterpret_cast<int*>(red + 64);
+      const int nw = width >> 6, wv = lane >> 6;
+      __syncthreads();
+      if ((lane & 63) == 0) { rb[wv] = b; rp[wv] = p; }
+      __syncthreads();
+      b = rb[0];
+      p = rp[0];
+      for (int i = 1; i < nw; ++i) {
+        if (rb[i] > b || (rb[i] == b && rp[i] < p)) { b = rb[i]; p = rp[i]; }
+      }
     }
     *best = b;
     return p;
@@ -243,7 +259,7 @@ __global__ void __launch_bounds__(64) k_wave_for(int64_t n, size_t lds_per_item,
   for (int64_t b0 = (int64_t)blockIdx.x * per_block; b0 < n; b0 += (int64_t)gridDim.x * per_block) {
     const int64_t b = b0 + grp;
     if (b < n) {
-      WaveCtx w{b, pfv_lds + (size_t)grp * lds_per_item, (int)threadIdx.x % G, G};
+      WaveCtx w{b, pfv_lds + (size_t)grp * lds_per_item, (int)threadIdx.x % G, G, nullptr};
       f(w);
     }
     __syncthreads();
@@ -275,7 +291,7 @@ inline void wave_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
   (void)s;
   std::vector<double> lds((lds_bytes + 7) / 8 + 2);
   for (int64_t b = 0; b < n; ++b) {
-    WaveCtx w{b, reinterpret_cast<char*>(lds.data()), 0, 1};
+    WaveCtx w{b, reinterpret_cast<char*>(lds.data()), 0, 1, nullptr};
     f(w);
   }
 #else
@@ -291,6 +307,43 @@ inline void wave_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
   }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wave_for<G, F>), dim3((unsigned)blocks), dim3(64), block_lds, s, n,
                      lds_bytes, f);
+  PFV_HIP_CHECK(hipGetLastError());
+#endif
+}
+
+// T threads (several wavefronts) per work item, one item per workgroup: for work items whose LDS
+// footprint allows only one of them per CU anyway (MPSA interaction regions, ~140 KB).
+#ifndef PFV_EMULATE
+template <int T, class F>
+__global__ void __launch_bounds__(T) k_block_for(int64_t n, size_t lds_bytes, F f) {
+  extern __shared__ __attribute__((aligned(16))) char pfv_lds[];
+  for (int64_t b = blockIdx.x; b < n; b += gridDim.x) {
+    WaveCtx w{b, pfv_lds, (int)threadIdx.x, T, pfv_lds + lds_bytes};
+    f(w);
+    __syncthreads();
+  }
+}
+#endif
+template <int T = 256, class F>
+inline void block_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
+  if (n <= 0) return;
+  lds_bytes = (lds_bytes + 15) & ~size_t(15);
+#ifdef PFV_EMULATE
+  (void)s;
+  std::vector<double> lds((lds_bytes + 7) / 8 + 2);
+  for (int64_t b = 0; b < n; ++b) {
+    WaveCtx w{b, reinterpret_cast<char*>(lds.data()), 0, 1, nullptr};
+    f(w);
+  }
+#else
+  const size_t total = lds_bytes + 128;
+  if (total > 160 * 1024) throw Error(5, "work item needs more than 160 KiB of LDS");
+  int64_t blocks = n < 256 * 8 ? n : 256 * 8;
+  if (total > 48 * 1024) {
+    PFV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_for<T, F>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)total));
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_for<T, F>), dim3((unsigned)blocks), dim3(T), total, s, n, lds_bytes, f);
   PFV_HIP_CHECK(hipGetLastError());
 #endif
 }

@@ -27,6 +27,16 @@ struct CsrPattern {
   int max_row = 0;
 };
 
+// a square system the Krylov solver can work on (flow: A = div flux; mechanics: A = div_nd stress)
+struct LinSys {
+  const CsrPattern* P = nullptr;
+  double* val = nullptr;
+  double* diag = nullptr;
+  double* rhs = nullptr;
+  int64_t n = 0;
+  bool valid = false;
+};
+
 struct pfv_ctx_impl {
   int device = 0;
   stream_t stream{};      // stream all work of this handle is issued on
@@ -76,7 +86,7 @@ struct pfv_ctx_impl {
   double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {1, 1, 1};
   Buf<int32_t> node_order;    // [nn] nodes sorted by block-size class
   std::vector<int64_t> class_begin;  // host: first position of each size class in node_order
-  int max_block = 0, max_deg = 0, max_face_nodes = 0, max_cell_faces = 0;
+  int max_block = 0, max_deg = 0, max_face_nodes = 0, max_cell_faces = 0, max_bnd_per_node = 0;
   int64_t sum_block_sq = 0;
 
   // ---- per-node numeric results consumed by the face kernel ---------------------
@@ -93,10 +103,24 @@ struct pfv_ctx_impl {
   bool have_symbolic = false, have_numeric = false, have_system = false;
   CsrPattern pat_flux, pat_bound, pat_vs, pat_A;  // bound_pressure_* share flux / bound patterns
   Buf<double> val[PFV_NUM_MATS];
-  bool filled[PFV_NUM_MATS] = {false, false, false, false, false, false, false};
+  bool filled[PFV_NUM_MATS] = {false, false, false, false, false, false, false, false, false, false, false, false};
   Buf<double> rhs, diag, xsol, face_tmp, vec_in;
   Buf<double> kry[10];
   Buf<double> red;  // reduction partials
+
+  // ---- MPSA -------------------------------------------------------------------------
+  bool have_mpsa_params = false, have_mpsa_numeric = false, have_mpsa_symbolic = false, have_mech_system = false;
+  Buf<double> stiff;                 // [81][Nc]: stiff[(9*q + r)*Nc + c] = C_qr(c)
+  Buf<double> cvol;                  // [nc] cell volumes (node-volume weights of the asymmetric part)
+  Buf<uint8_t> bc_dirbits, bc_neubits;
+  double mpsa_eta = 0.0;
+  Buf<int32_t> cell_nnodes;          // [nc] distinct nodes of a cell (node-volume weights)
+  Buf<int64_t> node_eptr, node_ebptr;  // [nn+1] offsets of the per-node expanded rows (cells / boundary faces)
+  Buf<double> Es, Et, Esb, Etb;      // per node: (nd*nsf) x (nd*deg) stress / trace rows; x (nd*nb) boundary
+  CsrPattern pat_stress, pat_bstress, pat_Am;
+  std::vector<int32_t> mpsa_class_lds;  // LDS bytes of the largest node per block-size class
+  Buf<double> rhs_m, diag_m;
+  LinSys active;                     // what pfv_solve / pfv_get_rhs operate on
 
   pfv_stats stats{};
 
@@ -111,6 +135,14 @@ struct pfv_ctx_impl {
       case PFV_MAT_VECTOR_SOURCE:
       case PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE:
         return pat_vs;
+      case PFV_MAT_STRESS:
+      case PFV_MAT_BOUND_DISPLACEMENT_CELL:
+        return pat_stress;
+      case PFV_MAT_BOUND_STRESS:
+      case PFV_MAT_BOUND_DISPLACEMENT_FACE:
+        return pat_bstress;
+      case PFV_MAT_MECH_SYSTEM:
+        return pat_Am;
       default:
         return pat_A;
     }

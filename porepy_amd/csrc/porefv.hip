@@ -9,6 +9,7 @@
 #include "topology.inc"
 #include "mpfa_numeric.inc"
 #include "linalg.inc"
+#include "mpsa.inc"
 
 using pfv::be_d2h;
 using pfv::be_h2d;
@@ -145,6 +146,8 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     upload(h->fn_idx, fn_indices, (size_t)h->nsf, s);
     h->have_grid = true;
     h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
+    h->have_mpsa_numeric = h->have_mpsa_symbolic = h->have_mech_system = false;
+    h->active.valid = false;
     for (bool& f : h->filled) f = false;
   });
 }
@@ -204,7 +207,7 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
 pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
-    require(h->have_symbolic, "discretize first");
+    require(which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic, "discretize first");
     const pfv::CsrPattern& P = h->pattern_of(which);
     if (nrows) *nrows = P.nrows;
     if (ncols) *ncols = P.ncols;
@@ -215,7 +218,7 @@ pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols
 pfv_status pfv_get_matrix(pfv_ctx* h, int which, int32_t* indptr, int32_t* indices, double* data) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
-    require(h->have_symbolic, "discretize first");
+    require(which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic, "discretize first");
     const pfv::CsrPattern& P = h->pattern_of(which);
     auto s = h->stream;
     if (indptr) be_d2h(indptr, P.indptr.p, sizeof(int32_t) * (size_t)(P.nrows + 1), s);
@@ -248,13 +251,95 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     pfv::assemble_rhs(*h, d_bc, d_vs, d_src);
     h->stats.assemble_ms = tm.stop(s);
     h->have_system = true;
+    h->active.P = &h->pat_A;
+    h->active.val = h->val[PFV_MAT_SYSTEM].p;
+    h->active.diag = h->diag.p;
+    h->active.rhs = h->rhs.p;
+    h->active.n = h->nc;
+    h->active.valid = true;
+  });
+}
+
+pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const double* cell_volumes,
+                               const uint8_t* bc_dir_bits, const uint8_t* bc_neu_bits, double eta) {
+  return guarded(h, [&] {
+    require(h->have_grid, "pfv_set_grid must be called first");
+    require(stiffness_99n && cell_volumes && bc_dir_bits && bc_neu_bits, "null parameter array");
+    auto s = h->stream;
+    upload(h->stiff, stiffness_99n, 81 * (size_t)h->nc, s);
+    upload(h->cvol, cell_volumes, (size_t)h->nc, s);
+    upload(h->bc_dirbits, bc_dir_bits, (size_t)h->nf, s);
+    upload(h->bc_neubits, bc_neu_bits, (size_t)h->nf, s);
+    h->mpsa_eta = eta;
+    h->have_mpsa_params = true;
+    h->have_mpsa_numeric = h->have_mech_system = false;
+  });
+}
+
+pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_mpsa_params, "grid and MPSA parameters must be set before discretize");
+    auto s = h->stream;
+    pfv::Timer tm;
+    if (!h->have_topology || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
+      tm.start(s);
+      pfv::build_topology(*h);
+      h->stats.topology_ms = tm.stop(s);
+      tm.start(s);
+      pfv::build_symbolic(*h);
+      h->stats.symbolic_ms = tm.stop(s);
+      h->have_mpsa_symbolic = false;
+      h->have_numeric = h->have_system = false;
+    }
+    if (!h->have_mpsa_symbolic) {
+      tm.start(s);
+      pfv::mpsa_symbolic(*h);
+      h->stats.symbolic_ms += tm.stop(s);
+    }
+    tm.start(s);
+    pfv::mpsa_run_node_kernel(*h);
+    h->stats.node_ms = tm.stop(s);
+    tm.start(s);
+    pfv::mpsa_run_face_kernel(*h);
+    h->stats.face_ms = tm.stop(s);
+    h->have_mpsa_numeric = true;
+    h->have_mech_system = false;
+    h->filled[PFV_MAT_MECH_SYSTEM] = false;
+  });
+}
+
+pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* source) {
+  return guarded(h, [&] {
+    require(h->have_mpsa_numeric, "pfv_mpsa_discretize first");
+    require(bc_values != nullptr, "bc_values is required");
+    auto s = h->stream;
+    const size_t nfd = (size_t)h->nf * h->nd, ncd = (size_t)h->nc * h->nd;
+    double* in = h->vec_in.ensure(nfd + ncd);
+    be_h2d(in, bc_values, nfd * sizeof(double), s);
+    double* d_src = nullptr;
+    if (source) {
+      d_src = in + nfd;
+      be_h2d(d_src, source, ncd * sizeof(double), s);
+    }
+    pfv::Timer tm;
+    tm.start(s);
+    if (!h->have_mech_system) pfv::mpsa_assemble_system(*h);
+    pfv::mpsa_assemble_rhs(*h, in, d_src);
+    h->stats.assemble_ms = tm.stop(s);
+    h->have_mech_system = true;
+    h->active.P = &h->pat_Am;
+    h->active.val = h->val[PFV_MAT_MECH_SYSTEM].p;
+    h->active.diag = h->diag_m.p;
+    h->active.rhs = h->rhs_m.p;
+    h->active.n = h->nc * h->nd;
+    h->active.valid = true;
   });
 }
 
 pfv_status pfv_get_rhs(pfv_ctx* h, double* b) {
   return guarded(h, [&] {
-    require(h->have_system && b, "assemble first");
-    be_d2h(b, h->rhs.p, sizeof(double) * (size_t)h->nc, h->stream);
+    require(h->active.valid && b, "assemble first");
+    be_d2h(b, h->active.rhs, sizeof(double) * (size_t)h->active.n, h->stream);
   });
 }
 
@@ -341,18 +426,18 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
   (void)restart;
   pfv::SolveResult res;
   pfv_status st = guarded(h, [&] {
-    require(h->have_system, "assemble first");
+    require(h->active.valid, "assemble first");
     require(x != nullptr, "x is required");
     require(method == PFV_SOLVE_CG || method == PFV_SOLVE_BICGSTAB,
             "method must be PFV_SOLVE_CG or PFV_SOLVE_BICGSTAB");
     require(rtol > 0 && maxit > 0, "rtol and maxit must be positive");
     auto s = h->stream;
-    const size_t n = (size_t)h->nc;
+    const size_t n = (size_t)h->active.n;
     double* dx = h->xsol.ensure(n);
     if (x0) be_h2d(dx, x0, n * sizeof(double), s); else pfv::be_memset(dx, 0, n * sizeof(double), s);
     pfv::Timer tm;
     tm.start(s);
-    res = pfv::krylov_solve(*h, method, rtol, maxit, h->rhs.p, dx, x0 == nullptr);
+    res = pfv::krylov_solve(*h, h->active, method, rtol, maxit, dx, x0 == nullptr);
     h->stats.solve_ms = tm.stop(s);
     be_d2h(x, dx, n * sizeof(double), s);
   });

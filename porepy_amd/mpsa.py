@@ -1,0 +1,109 @@
+"""``Mpsa`` — the reference's MPSA-W stress discretization operator on an MI355X.
+
+Operator API of ``pp.Mpsa`` (numerics/fv/mpsa.py:63-529): ``Mpsa(keyword)``, ``ndof``,
+``discretize(sd, data)``, ``assemble_matrix_rhs(sd, data)``, four ``*_matrix_key`` attributes;
+parameters ``fourth_order_tensor``, ``bc`` (vectorial), ``bc_values`` ((nd, Nf) raveled "F"),
+``source``, ``mpsa_eta``.  Unknown ordering is cell-major, component-minor (u[nd*c + a]).
+Covered: component-wise Dirichlet / Neumann conditions in the Cartesian basis.  Robin conditions,
+rotated bases, sub-face conditions and partial updates raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .grid import grid_to_raw
+from .mpfa import determine_eta
+from .params import DISCRETIZATION_MATRICES, PARAMETERS
+
+_KEYS = (
+    ("stress", _lib.MAT_STRESS),
+    ("bound_stress", _lib.MAT_BOUND_STRESS),
+    ("bound_displacement_cell", _lib.MAT_BOUND_DISPLACEMENT_CELL),
+    ("bound_displacement_face", _lib.MAT_BOUND_DISPLACEMENT_FACE),
+)
+
+
+class Mpsa:
+    def __init__(self, keyword: str, device: int = 0, library=None):
+        self.keyword = keyword
+        self.device = device
+        self._library = library
+        self.stress_matrix_key = "stress"
+        self.bound_stress_matrix_key = "bound_stress"
+        self.bound_displacement_cell_matrix_key = "bound_displacement_cell"
+        self.bound_displacement_face_matrix_key = "bound_displacement_face"
+        self._contexts: dict = {}
+
+    def ndof(self, sd) -> int:
+        return sd.dim * sd.num_cells
+
+    def context(self, sd) -> _lib.Context:
+        ent = self._contexts.get(id(sd))
+        if ent is None or ent[0] is not sd:
+            if sd.dim not in (2, 3):
+                raise NotImplementedError("porepy_amd.Mpsa covers 2-D and 3-D grids")
+            ctx = _lib.Context(self.device, self._library)
+            ctx.set_grid(grid_to_raw(sd))
+            self._contexts[id(sd)] = (sd, ctx)
+            return ctx
+        return ent[1]
+
+    def discretize(self, sd, data: dict) -> None:
+        pd = data[PARAMETERS][self.keyword]
+        md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
+        C = pd["fourth_order_tensor"]
+        bnd = pd["bc"]
+        if np.asarray(bnd.is_dir).ndim != 2:
+            # same failure mode as the reference (mpsa.py:658-659)
+            raise AttributeError("MPSA must be given a vectorial boundary condition")
+        if np.any(getattr(bnd, "is_rob", False)):
+            raise NotImplementedError("Robin conditions are not covered by the device MPSA path yet")
+        basis = getattr(bnd, "basis", None)
+        if basis is not None and np.asarray(basis).ndim == 3:
+            eye = np.eye(sd.dim)[:, :, None]
+            if not np.allclose(basis, eye):
+                raise NotImplementedError("rotated boundary bases are not covered yet")
+        for key in ("specified_cells", "specified_faces", "specified_nodes"):
+            if pd.get(key) is not None:
+                raise NotImplementedError(f"partial discretization ({key}) is not covered yet")
+        eta = pd.get("mpsa_eta", None)
+        if eta is None:
+            eta = determine_eta(sd)
+        elif np.asarray(eta).size != 1:
+            raise NotImplementedError("per-sub-face eta is not covered for MPSA yet")
+        ctx = self.context(sd)
+        ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta))
+        try:
+            ctx.mpsa_discretize()
+        except _lib.PorefvError as e:
+            if e.status == 1:
+                raise ValueError("Error in inversion of local linear systems") from e
+            if e.status == 2:
+                raise AssertionError(e.message) from e
+            raise
+        for name, which in _KEYS:
+            md[name] = ctx.matrix(which)
+
+    def update_discretization(self, sd, data: dict) -> None:
+        self.discretize(sd, data)
+
+    def _assemble(self, sd, data):
+        pd = data[PARAMETERS][self.keyword]
+        ent = self._contexts.get(id(sd))
+        if ent is None or ent[0] is not sd:
+            raise RuntimeError("discretize(sd, data) must run on this object first")
+        ctx = ent[1]
+        src = pd.get("source", None)
+        ctx.mpsa_assemble(np.asarray(pd["bc_values"], dtype=float), src)
+        return ctx
+
+    def assemble_matrix_rhs(self, sd, data: dict):
+        """A = div_nd @ stress, b = -div_nd @ bound_stress @ bc_values + source (mpsa.py:486-529)."""
+        ctx = self._assemble(sd, data)
+        n = sd.dim * sd.num_cells
+        return ctx.matrix(_lib.MAT_MECH_SYSTEM), ctx.active_rhs(n)
+
+    def solve(self, sd, data: dict, method: str = "bicgstab", rtol: float = 1e-12, maxit: int = 50000, x0=None):
+        ctx = self._assemble(sd, data)
+        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, n=sd.dim * sd.num_cells)

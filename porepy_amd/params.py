@@ -109,3 +109,64 @@ def initialize_data(data: dict, keyword: str, specified_parameters: dict | None 
     data.setdefault(PARAMETERS, {}).setdefault(keyword, {}).update(specified_parameters or {})
     data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(keyword, {})
     return data
+
+
+class FourthOrderTensor:
+    """Cell-wise stiffness, ``values`` of shape (9, 9, Nc) with
+    ``values[3*i + k, 3*a + l, c] = C_{ik,al}`` (sigma_ik = sum C_{ik,al} d_l u_a), isotropic from
+    Lame parameters like the reference's constructor (params/tensor.py:251-349)."""
+
+    def __init__(self, mu, lmbda, other_fields=None):
+        mu = np.asarray(mu, dtype=float)
+        lmbda = np.asarray(lmbda, dtype=float)
+        if mu.ndim != 1 or lmbda.shape != mu.shape:
+            raise ValueError("mu and lmbda must be 1-D arrays of equal length")
+        nc = mu.size
+        v = np.zeros((9, 9, nc))
+        for i in range(3):
+            for j in range(3):
+                v[3 * i + i, 3 * j + j] += lmbda
+                v[3 * i + j, 3 * i + j] += mu
+                v[3 * i + j, 3 * j + i] += mu
+        self.values = v
+        self.mu = mu
+        self.lmbda = lmbda
+
+    def copy(self):
+        t = FourthOrderTensor(self.mu.copy(), self.lmbda.copy())
+        t.values = self.values.copy()
+        return t
+
+
+class BoundaryConditionVectorial:
+    """Component-wise boundary condition: is_dir / is_neu / is_rob of shape (nd, Nf)
+    (params/bc.py:222-322).  Default: every boundary face Neumann in every component."""
+
+    def __init__(self, sd, faces=None, cond=None):
+        nf, nd = sd.num_faces, sd.dim
+        self.num_faces = nf
+        self.dim = nd
+        self.is_neu = np.zeros((nd, nf), dtype=bool)
+        self.is_dir = np.zeros((nd, nf), dtype=bool)
+        self.is_rob = np.zeros((nd, nf), dtype=bool)
+        self.is_internal = np.zeros(nf, dtype=bool)
+        self.robin_weight = np.tile(np.eye(nd)[:, :, None], (1, 1, nf))
+        self.basis = np.tile(np.eye(nd)[:, :, None], (1, 1, nf))
+        bnd = sd.get_all_boundary_faces()
+        self.is_neu[:, bnd] = True
+        if faces is not None:
+            faces = np.asarray(faces)
+            if faces.dtype == bool:
+                faces = np.flatnonzero(faces)
+            if cond is None:
+                raise ValueError("Boundary condition type must be given with the faces")
+            if isinstance(cond, str):
+                cond = [cond] * faces.size
+            for f, c in zip(faces, cond):
+                s = c.lower()
+                if s == "dir":
+                    self.is_dir[:, f], self.is_neu[:, f] = True, False
+                elif s == "rob":
+                    self.is_rob[:, f], self.is_neu[:, f] = True, False
+                elif s != "neu":
+                    raise ValueError(f"Boundary should be Dirichlet, Neumann or Robin, not {c}")

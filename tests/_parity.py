@@ -165,3 +165,135 @@ def linear_field_exact(lib, g, tol=1e-11):
     q = mats["flux"] @ ones_c + mats["bound_flux"] @ ones_f
     assert np.max(np.abs(q)) < 1e-10 * abs(mats["flux"]).max()
     return info
+
+
+# ------------------------------------------------------------------------------------ MPSA
+from oracle import mpsa_oracle as so  # noqa: E402
+from tests._golden import MPSA_KEYS, MpsaCase  # noqa: E402
+
+MPSA_WHICH = dict(zip(MPSA_KEYS, (7, 8, 9, 10)))
+
+
+def run_mpsa_case(lib, c: MpsaCase):
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(c.grid)
+    eta = c.eta if c.eta is not None else mo.default_eta(c.grid["name"])
+    ctx.mpsa_set_params(c.stiffness, c.grid["cell_volumes"], c.bc["is_dir"], c.bc["is_neu"], eta)
+    ctx.mpsa_discretize()
+    return ctx
+
+
+def check_mpsa_golden_case(lib, name: str):
+    c = MpsaCase(name)
+    ctx = run_mpsa_case(lib, c)
+    ora = so.discretize(c.grid, c.stiffness, c.bc, eta=c.eta)
+    for k in MPSA_KEYS:
+        M = ctx.matrix(MPSA_WHICH[k])
+        assert M.indices.dtype == np.int32 and M.has_sorted_indices
+        assert np.array_equal(M.indptr, ora[k].indptr), (name, k)
+        assert np.array_equal(M.indices, ora[k].indices), (name, k)
+        assert rel_max_err(M, ora[k]) < TOL, (name, k)
+        if k in c.ref:
+            assert rel_max_err(M, c.ref[k]) < TOL, (name, k)
+            subset, outside, _ = check_pattern(M, c.ref[k])
+            assert subset and outside < 1e-12, (name, k, outside)
+    ctx.mpsa_assemble(c.bc_values, c.source)
+    A = ctx.matrix(pa._lib.MAT_MECH_SYSTEM)
+    n = A.shape[0]
+    b = ctx.active_rhs(n)
+    assert rel_max_err(A, c.ref["A"]) < TOL
+    assert np.linalg.norm(b - c.ref_rhs) <= TOL * max(np.linalg.norm(c.ref_rhs), 1e-300)
+    x, info = ctx.solve("bicgstab", rtol=1e-13, maxit=20000, n=n)
+    assert info["converged"]
+    res = np.linalg.norm(c.ref_rhs - c.ref["A"] @ x) / max(np.linalg.norm(c.ref_rhs), 1e-300)
+    assert res < 1e-10, (name, res)
+    if "hetero" not in name:
+        assert np.linalg.norm(x - c.ref_x) <= 1e-8 * np.linalg.norm(c.ref_x), name
+    ctx.close()
+
+
+def check_mpsa_known_answer(lib, key: str):
+    """The reference's golden displacement / traction vectors (test_mpsa.py:1296-1323)."""
+    c = MpsaCase("mpsa_known_" + key)
+    ctx = run_mpsa_case(lib, c)
+    ctx.mpsa_assemble(c.bc_values, c.known_rhs)
+    n = c.grid["dim"] * c.grid["cell_centers"].shape[1]
+    u, info = ctx.solve("bicgstab", rtol=1e-13, maxit=20000, n=n)
+    stress = ctx.spmv(pa._lib.MAT_STRESS, u) + ctx.spmv(pa._lib.MAT_BOUND_STRESS, c.bc_values)
+    assert np.allclose(u, c.known_u)
+    assert np.allclose(stress, c.known_stress)
+
+
+def mpsa_uniaxial_exact(lib, g, tol=1e-10):
+    """BASELINE config C4 recipe: mu = lambda = 1, rollers on the low x/y/z faces, unit traction on
+    top; exact u = (nu x / E, nu y / E, -z / E), E = 2.5, nu = 0.25."""
+    nd = g.dim
+    nc, nf = g.num_cells, g.num_faces
+    C = pa.FourthOrderTensor(np.ones(nc), np.ones(nc))
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    fc = g.face_centers
+    for axis in range(nd):
+        roll = bf[fc[axis, bf] < 1e-9]
+        bc.is_dir[axis, roll] = True
+        bc.is_neu[axis, roll] = False
+    bv = np.zeros((nd, nf))
+    top = bf[fc[nd - 1, bf] > fc[nd - 1].max() - 1e-9]
+    bv[nd - 1, top] = -1.0 * g.face_areas[top]
+    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "bc_values": bv.ravel("F")})
+    d = pa.Mpsa("mechanics", library=lib)
+    d.discretize(g, data)
+    u, info = d.solve(g, data, rtol=1e-13)
+    assert info["converged"]
+    u = u.reshape(nd, -1, order="F")
+    cc = g.cell_centers
+    if nd == 3:
+        E, nu = 2.5, 0.25
+        exact = np.vstack((nu * cc[0] / E, nu * cc[1] / E, -cc[2] / E))
+    else:  # plane strain: sigma_yy = -1, eps_xx free in x only
+        lam = mu = 1.0
+        eyy = -1.0 / (lam + 2 * mu - lam * lam / (lam + 2 * mu))
+        exx = -lam / (lam + 2 * mu) * eyy
+        exact = np.vstack((exx * cc[0], eyy * cc[1]))
+    assert np.max(np.abs(u - exact)) < tol, np.max(np.abs(u - exact))
+    return info
+
+
+def mpsa_operator_roundtrip(lib, g, seed=0, mode="clamped_bottom"):
+    """Mpsa operator API on one of this package's grids vs the oracle (heterogeneous Lame
+    parameters, bottom clamped or rollers on the low-x side, Neumann elsewhere)."""
+    rng = np.random.default_rng(seed)
+    nd, nc, nf = g.dim, g.num_cells, g.num_faces
+    het = np.where(g.cell_centers[0] > 0.5 * g.nodes[0].max(), 50.0, 1.0)
+    C = pa.FourthOrderTensor(het * (1 + rng.random(nc)), het * (1 + rng.random(nc)))
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    bot = bf[g.face_centers[nd - 1, bf] < 1e-9]
+    bc.is_dir[:, bot] = True
+    bc.is_neu[:, bot] = False
+    if mode == "roller":
+        west = bf[g.face_centers[0, bf] < 1e-9]
+        bc.is_dir[0, west] = True
+        bc.is_neu[0, west] = False
+        bc.is_dir[1:, west] = False
+        bc.is_neu[1:, west] = True
+    bv = (rng.random((nd, nf)) - 0.4) * (bc.is_dir | bc.is_neu)
+    src = 0.1 * rng.random(nd * nc)
+    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc,
+                                                "bc_values": bv.ravel("F"), "source": src})
+    d = pa.Mpsa("mechanics", library=lib)
+    d.discretize(g, data)
+    raw = pa.grid_to_raw(g)
+    ora = so.discretize(raw, C.values, {"is_dir": bc.is_dir, "is_neu": bc.is_neu})
+    mats = data[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    for k in MPSA_KEYS:
+        assert np.array_equal(mats[k].indices, ora[k].indices), k
+        assert rel_max_err(mats[k], ora[k]) < TOL, k
+    A, b = d.assemble_matrix_rhs(g, data)
+    Ao, bo = so.assemble_matrix_rhs(raw, ora, bv.ravel("F"), src)
+    assert rel_max_err(A, Ao) < TOL
+    assert np.linalg.norm(b - bo) <= TOL * np.linalg.norm(bo)
+    x, info = d.solve(g, data, rtol=1e-13)
+    assert info["converged"]
+    assert np.linalg.norm(bo - Ao @ x) <= 1e-10 * np.linalg.norm(bo)
+    return d, data

@@ -1,0 +1,66 @@
+"""CPU suite for the MPSA path: host-emulation build of the kernels vs oracle / reference."""
+import numpy as np
+import pytest
+
+import porepy_amd as pa
+from tests import _parity as P
+from tests._golden import mpsa_case_names
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return P.emulation_library()
+
+
+def _geo(g):
+    g.compute_geometry()
+    return g
+
+
+@pytest.mark.parametrize("name", mpsa_case_names())
+def test_mpsa_golden_case(lib, name):
+    P.check_mpsa_golden_case(lib, name)
+
+
+@pytest.mark.parametrize("key", ["cart_homogeneous", "cart_heterogeneous",
+                                 "simplex_homogeneous", "simplex_heterogeneous"])
+def test_mpsa_reference_known_answers(lib, key):
+    P.check_mpsa_known_answer(lib, key)
+
+
+@pytest.mark.parametrize("make", [
+    lambda: pa.perturb_interior_nodes(_geo(pa.StructuredTriangleGrid([4, 4], [1, 1])), 0.05),
+    lambda: pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([2, 2, 3], [1, 1, 1])), 0.05),
+])
+def test_mpsa_uniaxial_solution_is_exact(lib, make):
+    # (simplex grids: with eta = 0 on Cartesian grids two rollers meeting in a corner give a
+    #  singular local system in the reference as well)
+    g = make()
+    g.compute_geometry()
+    P.mpsa_uniaxial_exact(lib, g)
+
+
+@pytest.mark.parametrize("make,mode", [
+    (lambda: pa.CartGrid([4, 3], [1, 1]), "roller"),
+    (lambda: pa.CartGrid([3, 3, 2], [1, 1, 1]), "clamped_bottom"),
+    (lambda: pa.perturb_interior_nodes(_geo(pa.StructuredTriangleGrid([4, 3], [1, 1])), 0.05), "roller"),
+    (lambda: pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([2, 2, 2], [1, 1, 1])), 0.05), "roller"),
+])
+def test_mpsa_operator_api_vs_oracle(lib, make, mode):
+    g = make()
+    g.compute_geometry()
+    P.mpsa_operator_roundtrip(lib, g, mode=mode)
+
+
+def test_mpsa_rejects_what_it_does_not_cover(lib):
+    g = _geo(pa.CartGrid([3, 3], [1, 1]))
+    C = pa.FourthOrderTensor(np.ones(9), np.ones(9))
+    bc = pa.BoundaryCondition(g)  # scalar bc -> same AttributeError as the reference
+    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc})
+    with pytest.raises(AttributeError):
+        pa.Mpsa("mechanics", library=lib).discretize(g, data)
+    bcv = pa.BoundaryConditionVectorial(g)
+    bcv.is_rob[0, g.get_all_boundary_faces()[0]] = True
+    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bcv})
+    with pytest.raises(NotImplementedError):
+        pa.Mpsa("mechanics", library=lib).discretize(g, data)

@@ -1,0 +1,59 @@
+"""GPU suite (-m gpu) for the MPSA path: gfx950 HIP library vs oracle, reference fixtures and
+exact solutions.  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+import porepy_amd as pa
+from tests import _parity as P
+from tests._golden import mpsa_case_names
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return pa._lib.product_library()
+
+
+def _geo(g):
+    g.compute_geometry()
+    return g
+
+
+@pytest.mark.parametrize("name", mpsa_case_names())
+def test_mpsa_golden_case(lib, name):
+    P.check_mpsa_golden_case(lib, name)
+
+
+@pytest.mark.parametrize("key", ["cart_homogeneous", "cart_heterogeneous",
+                                 "simplex_homogeneous", "simplex_heterogeneous"])
+def test_mpsa_reference_known_answers(lib, key):
+    P.check_mpsa_known_answer(lib, key)
+
+
+@pytest.mark.parametrize("make,mode", [
+    (lambda: pa.CartGrid([12, 9], [1, 1]), "roller"),
+    (lambda: pa.CartGrid([5, 4, 4], [1, 1, 1]), "clamped_bottom"),
+    (lambda: pa.perturb_interior_nodes(_geo(pa.StructuredTriangleGrid([9, 8], [1, 1])), 0.03), "roller"),
+    (lambda: pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([4, 4, 4], [1, 1, 1])), 0.04), "roller"),
+])
+def test_mpsa_operator_api_vs_oracle(lib, make, mode):
+    g = make()
+    g.compute_geometry()
+    P.mpsa_operator_roundtrip(lib, g, mode=mode)
+
+
+def test_mpsa_uniaxial_exact_mid_size(lib):
+    """Config C4 recipe at 10^3 * 6 tetrahedra: exact uniaxial solution (size-independent)."""
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([10, 10, 10], [1, 1, 1])), 0.02)
+    P.mpsa_uniaxial_exact(lib, g, tol=1e-9)
+
+
+def test_mpsa_deterministic_bitwise(lib):
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([4, 4, 4], [1, 1, 1])), 0.03)
+    d1, data1 = P.mpsa_operator_roundtrip(lib, g, seed=2)
+    d2, data2 = P.mpsa_operator_roundtrip(lib, g, seed=2)
+    for k in ("stress", "bound_stress", "bound_displacement_cell"):
+        a = data1[pa.DISCRETIZATION_MATRICES]["mechanics"][k]
+        b = data2[pa.DISCRETIZATION_MATRICES]["mechanics"][k]
+        assert np.array_equal(a.data, b.data), k
