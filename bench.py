@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-side", type=int, default=69, help="lattice cells per side (6 tets each)")
     ap.add_argument("--rtol", type=float, default=1e-10)
-    ap.add_argument("--cpu-n-side", type=int, default=12)
+    ap.add_argument("--cpu-n-side", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     args = ap.parse_args()
@@ -258,9 +258,17 @@ def main():
     spmv_ms = ctx.time_kernel(0, reps=50)
     spmv_bytes = 12.0 * nnzA + 4.0 * (nloc + 1) + 8.0 * nloc + 8.0 * nloc  # values+indices, indptr, x, y
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    traffic = None  # PMC measurement of the same launch on the same workload (profiles/), else null
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_spmv.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("n_side") == args.n_side and world == 1:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": "k_spmv (CSR SpMV with A, 2 launches per BiCGStab iteration)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms}
+                "traffic": traffic, "bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms}
     # assembly kernels (HBM-bound on their CSR output): algorithmic bytes = inputs once + outputs once
     nnz = {k: ctx.matrix_info(i)[2] for i, k in enumerate(("flux", "bound_flux", "bpc", "bpf", "vs", "bpvs"))}
     out_bytes = 8.0 * sum(nnz.values()) + 4.0 * (nnz["flux"] + nnz["bound_flux"] + nnz["vs"]) + 12.0 * nnzA
