@@ -149,14 +149,22 @@ class Mpfa:
         return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0)
 
 
-def as_porepy_discretization():
-    """Subclass of the reference's ``pp.Mpfa`` whose hot path runs on the MI355X."""
+def as_porepy_discretization(device: int = 0, library=None):
+    """Subclass of the reference's ``pp.Mpfa`` whose hot path runs on the MI355X.
+    (``library`` is for tests that bind the host-emulation build; the product default is the
+    gfx950 library.)"""
     import porepy as pp  # the reference; absent on the GPU box
 
-    class HipMpfa(pp.Mpfa):  # type: ignore[misc]
-        def __init__(self, keyword: str, device: int = 0):
-            super().__init__(keyword)
-            self._hip = Mpfa(keyword, device)
+    _device, _library = device, library
+    _RefMpfa = pp.Mpfa
+
+    class HipMpfa(_RefMpfa):  # type: ignore[misc]
+        def __init__(self, keyword: str):
+            # pp.Mpfa.__init__ resolves ``super(pp.Mpfa, self)`` through the module attribute
+            # (mpfa.py:62-63), which recurses once pp.Mpfa is rebound to this class — go to
+            # its base (FVElliptic) directly
+            super(_RefMpfa, self).__init__(keyword)
+            self._hip = Mpfa(keyword, _device, _library)
 
         def discretize(self, sd, data):
             if sd.dim < 2:

@@ -1,0 +1,78 @@
+"""Run inside a subprocess with the REFERENCE PorePy importable (oracle/shim + /root/reference/src):
+a stock SinglePhaseFlow model (BASELINE config C1: 50x50 Cartesian, Mpfa) run twice — untouched,
+and with ``pp.Mpfa`` rebound to the porepy_amd operator (host-emulation library, because this
+container has no GPU) — must produce the same pressure field and the same Jacobian."""
+import json
+import sys
+
+import numpy as np
+
+import porepy as pp
+from porepy.applications.md_grids.domains import nd_cube_domain
+from porepy.models.fluid_mass_balance import SinglePhaseFlow
+
+import porepy_amd as pa
+from tests import _parity as P
+
+
+class Geometry:
+    def set_domain(self):
+        self._domain = nd_cube_domain(2, 1.0)
+
+    def grid_type(self):
+        return "cartesian"
+
+    def meshing_arguments(self):
+        return {"cell_size": 1.0 / 50}
+
+
+class BCs:
+    def bc_type_darcy_flux(self, sd):
+        sides = self.domain_boundary_sides(sd)
+        return pp.BoundaryCondition(sd, sides.west + sides.east, "dir")
+
+    def bc_values_pressure(self, bg):
+        sides = self.domain_boundary_sides(bg)
+        v = np.zeros(bg.num_cells)
+        v[sides.west] = 5.0
+        v[sides.east] = 2.0
+        return v
+
+
+class Model(Geometry, BCs, SinglePhaseFlow):
+    pass
+
+
+def run():
+    params = {"times_to_export": [], "linear_solver": "scipy_sparse",
+              "darcy_flux_discretization": "mpfa"}
+    m = Model(params)
+    pp.run_time_dependent_model(m, params)
+    sd = m.mdg.subdomains()[0]
+    p = m.equation_system.get_variable_values([m.pressure_variable], time_step_index=0)
+    A, b = m.linear_system
+    return sd.num_cells, np.asarray(p), A.copy(), np.asarray(b).copy()
+
+
+ref = run()
+calls = {"n": 0}
+HipMpfa = pa.as_porepy_discretization(library=P.emulation_library())
+orig = HipMpfa.discretize
+
+
+def counting(self, sd, data):
+    calls["n"] += 1
+    return orig(self, sd, data)
+
+
+HipMpfa.discretize = counting
+pp.Mpfa = HipMpfa
+ours = run()
+out = {
+    "cells": int(ref[0]),
+    "calls_into_device_path": calls["n"],
+    "p_rel_err": float(np.linalg.norm(ours[1] - ref[1]) / np.linalg.norm(ref[1])),
+    "p_sum_ref": float(ref[1].sum()),
+    "A_rel_err": float(abs(ours[2] - ref[2]).max() / abs(ref[2]).max()),
+}
+print("RESULT " + json.dumps(out))

@@ -1,0 +1,28 @@
+"""Drop-in check against the reference package itself (build container only; skipped where
+/root/reference is absent): an unmodified PorePy model runs with ``pp.Mpfa`` rebound."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference PorePy not present")
+def test_single_phase_flow_model_with_rebound_mpfa():
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "oracle", "shim"), REF, ROOT])
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dropin_script.py")], env=env, cwd="/tmp",
+                       capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, r.stderr[-2000:]
+    out = json.loads(line[-1][7:])
+    assert out["cells"] == 2500
+    assert out["calls_into_device_path"] >= 1
+    assert out["p_rel_err"] < 1e-10
+    assert out["A_rel_err"] < 1e-10  # (the final residual vector is round-off in both runs)
+    assert abs(out["p_sum_ref"] - 8750.0) < 1e-6  # config C1 of the reference
