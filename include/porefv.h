@@ -120,6 +120,17 @@ pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t
 /* Mpfa._flux_discretization (numerics/fv/mpfa.py:592-1156) on the device. */
 pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags);
 
+/* Partial (re)discretization: the node-list launch behind ``specified_cells / _faces /
+ * _nodes`` (numerics/fv/mpfa.py:178-204, 466-508) and ``update_discretization``
+ * (mpfa.py:510-590, _fvutils.py:1090-1257).  ``faces`` = the faces whose rows are to be
+ * computed (the reference's ``active_faces``, _fvutils.py:1260-1462, computed by the host);
+ * the interaction regions of their nodes are re-solved with the current parameters and
+ * exactly these rows of the six matrices are rewritten.  keep_other_rows = 0: every other
+ * row is zeroed (``specified_*`` semantics); 1: other rows keep the previous discretization
+ * (update semantics; requires an earlier discretize on this handle). */
+pfv_status pfv_mpfa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces,
+                                     const int32_t* faces, int keep_other_rows);
+
 /* shape and nnz of a produced matrix */
 pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols,
                            int64_t* nnz);

@@ -7,17 +7,18 @@ reached through the C ABI of ``include/porefv.h``.
 """
 from . import _lib
 from ._lib import Context, PorefvError
-from .grid import (CartGrid, Grid, StructuredTetrahedralGrid, StructuredTriangleGrid, grid_to_raw,
-                   perturb_interior_nodes)
+from .grid import (CartGrid, Grid, StructuredTetrahedralGrid, StructuredTriangleGrid, grid_from_raw,
+                   grid_to_raw, perturb_interior_nodes)
 from .mpfa import Mpfa, as_porepy_discretization, determine_eta
 from .mpsa import Mpsa
+from .partial import active_indices
 from .params import (DISCRETIZATION_MATRICES, PARAMETERS, BoundaryCondition, BoundaryConditionVectorial,
                      FourthOrderTensor, SecondOrderTensor, bc_flags, bc_to_raw, initialize_data)
 
 __all__ = [
     "Context", "PorefvError", "Grid", "CartGrid", "StructuredTriangleGrid",
-    "StructuredTetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "Mpfa",
+    "StructuredTetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "grid_from_raw", "Mpfa",
     "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition", "Mpsa",
     "FourthOrderTensor", "BoundaryConditionVectorial",
-    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib",
+    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices",
 ]

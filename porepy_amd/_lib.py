@@ -34,6 +34,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
+    "pfv_mpfa_discretize_faces",
 ]
 
 
@@ -84,6 +85,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpfa_set_params.restype = C.c_int
     lib.pfv_mpfa_discretize.argtypes = [_h, C.c_uint32]
     lib.pfv_mpfa_discretize.restype = C.c_int
+    lib.pfv_mpfa_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int]
+    lib.pfv_mpfa_discretize_faces.restype = C.c_int
     lib.pfv_matrix_info.argtypes = [_h, C.c_int, _lp, _lp, _lp]
     lib.pfv_matrix_info.restype = C.c_int
     lib.pfv_get_matrix.argtypes = [_h, C.c_int, _ip, _ip, _dp]
@@ -170,6 +173,7 @@ class Context:
             raise PorefvError(st, "pfv_create failed: no usable MI355X / HIP device "
                                   "(the product path has no CPU fallback)")
         self.nd = self.nc = self.nf = self.nn = 0
+        self._discretized = False  # a complete MPFA discretization is resident on the device
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -188,6 +192,7 @@ class Context:
 
     # ---- inputs -------------------------------------------------------------------
     def set_grid(self, raw: dict):
+        self._discretized = False
         nd = int(raw["dim"])
         nodes = _f64(raw["nodes"]); fn_ = _f64(raw["face_normals"]); fc = _f64(raw["face_centers"])
         cc = _f64(raw["cell_centers"]); fa = _f64(raw["face_areas"])
@@ -254,14 +259,28 @@ class Context:
         flags = (DISCR_REBUILD_TOPOLOGY if rebuild_topology else 0) | \
                 (DISCR_SKIP_VECTOR_SOURCE if skip_vector_source else 0)
         self._check(self.lib.pfv_mpfa_discretize(self._h, flags))
+        self._discretized = True
+
+    @property
+    def has_discretization(self) -> bool:
+        return self._discretized
+
+    def discretize_faces(self, faces, keep_other_rows: bool, skip_vector_source=False):
+        """Recompute the rows of ``faces`` only (partial discretization / update)."""
+        fa = np.ascontiguousarray(faces, dtype=np.int32)
+        flags = DISCR_SKIP_VECTOR_SOURCE if skip_vector_source else 0
+        self._check(self.lib.pfv_mpfa_discretize_faces(self._h, flags, fa.size, _ptr(fa, _ip),
+                                                       1 if keep_other_rows else 0))
+        self._discretized = self._discretized and bool(keep_other_rows)
 
     def matrix_info(self, which: int):
         r, c, z = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self.lib.pfv_matrix_info(self._h, which, C.byref(r), C.byref(c), C.byref(z)))
         return r.value, c.value, z.value
 
-    def matrix(self, which: int):
-        """Copy a result matrix to the host as scipy csr (int32 sorted indices, FP64)."""
+    def matrix(self, which: int, rows=None):
+        """Copy a result matrix to the host as scipy csr (int32 sorted indices, FP64).
+        ``rows``: keep only these rows (all others come back empty, the shape is unchanged)."""
         import scipy.sparse as sps
 
         nrows, ncols, nnz = self.matrix_info(which)
@@ -270,6 +289,13 @@ class Context:
         data = np.empty(nnz, dtype=np.float64)
         self._check(self.lib.pfv_get_matrix(self._h, which, _ptr(indptr, _ip), _ptr(indices, _ip),
                                             _ptr(data, _dp)))
+        if rows is not None:
+            keep = np.zeros(nrows, dtype=bool)
+            keep[np.asarray(rows, dtype=np.int64)] = True
+            lens = np.where(keep, np.diff(indptr), 0).astype(np.int32)
+            sel = np.repeat(keep, np.diff(indptr))
+            indices, data = indices[sel], data[sel]
+            indptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
         return sps.csr_matrix((data, indices, indptr), shape=(nrows, ncols))
 
     def assemble(self, bc_values, vector_source=None, source=None):

@@ -81,6 +81,8 @@ struct pfv_ctx_impl {
   Buf<int64_t> node_mptr;     // [nn+1] prefix of n(v)^2: offset of the node's n x n blocks
   Buf<SfMeta> sf_meta;        // [nsf] see SfMeta
   Buf<uint8_t> flux_colpairs; // [nnz(flux) * max_face_nodes] for every flux column: the (node of face, cell) pair per node, 0xff = none
+  Buf<uint8_t> node_active;   // [nn] partial discretization: nodes of the requested faces
+  Buf<int32_t> face_subset;   // partial discretization: the requested faces
   Buf<int32_t> face_order;    // [nf] faces along a Morton curve of their centres: processing order of the
                               //      face kernels, so that faces sharing nodes run close in time (L2 reuse)
   double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {1, 1, 1};
@@ -101,6 +103,7 @@ struct pfv_ctx_impl {
 
   // ---- outputs --------------------------------------------------------------------
   bool have_symbolic = false, have_numeric = false, have_system = false;
+  bool rows_complete = false;  // every row of the six MPFA matrices holds a discretization (maybe of older parameters)
   CsrPattern pat_flux, pat_bound, pat_vs, pat_A;  // bound_pressure_* share flux / bound patterns
   Buf<double> val[PFV_NUM_MATS];
   bool filled[PFV_NUM_MATS] = {false, false, false, false, false, false, false, false, false, false, false, false};

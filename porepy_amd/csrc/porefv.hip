@@ -146,6 +146,7 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     upload(h->fn_idx, fn_indices, (size_t)h->nsf, s);
     h->have_grid = true;
     h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
+    h->rows_complete = false;
     h->have_mpsa_numeric = h->have_mpsa_symbolic = h->have_mech_system = false;
     h->active.valid = false;
     for (bool& f : h->filled) f = false;
@@ -195,12 +196,68 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
     pfv::run_face_kernel(*h, with_vs);
     h->stats.face_ms = tm.stop(s);
     h->have_numeric = true;
+    h->rows_complete = true;
     h->have_system = false;
     h->filled[PFV_MAT_SYSTEM] = false;
     double bytes = 0.0;
     bytes += 2.0 * 8.0 * (double)h->pat_flux.nnz + 2.0 * 8.0 * (double)h->pat_bound.nnz;
     if (with_vs) bytes += 2.0 * 8.0 * (double)h->pat_vs.nnz;
     h->stats.bytes_written_outputs = bytes;
+  });
+}
+
+pfv_status pfv_mpfa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces, const int32_t* faces,
+                                     int keep_other_rows) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_params, "grid and parameters must be set before discretize");
+    require(n_faces >= 0 && (n_faces == 0 || faces), "bad face list");
+    require(!keep_other_rows || h->rows_complete,
+            "update of a discretization that was never computed on this handle");
+    for (int64_t i = 0; i < n_faces; ++i)
+      require(faces[i] >= 0 && faces[i] < h->nf, "face index out of range");
+    auto s = h->stream;
+    pfv::Timer tm;
+    if (!h->have_topology || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
+      require(!keep_other_rows, "the topology cannot be rebuilt under an update");
+      tm.start(s);
+      pfv::build_topology(*h);
+      h->stats.topology_ms = tm.stop(s);
+      tm.start(s);
+      pfv::build_symbolic(*h);
+      h->stats.symbolic_ms = tm.stop(s);
+    }
+    const bool with_vs = !(flags & PFV_DISCR_SKIP_VECTOR_SOURCE);
+    int32_t* sub = h->face_subset.ensure(std::max<int64_t>(n_faces, 1));
+    uint8_t* act = h->node_active.ensure(h->nn);
+    pfv::be_h2d(sub, faces, sizeof(int32_t) * (size_t)n_faces, s);
+    pfv::be_memset(act, 0, (size_t)h->nn, s);
+    const int32_t* fn_ptr = h->fn_ptr;
+    const int32_t* fn_idx = h->fn_idx;
+    pfv::parallel_for(s, n_faces, PFV_LAMBDA(int64_t i) {
+      const int f = sub[i];
+      for (int e = fn_ptr[f]; e < fn_ptr[f + 1]; ++e) act[fn_idx[e]] = 1;
+    });
+    tm.start(s);
+    pfv::run_node_kernel(*h, act);
+    h->stats.node_ms = tm.stop(s);
+    if (!keep_other_rows) {
+      h->rows_complete = false;
+      const int mats[6] = {PFV_MAT_FLUX, PFV_MAT_BOUND_FLUX, PFV_MAT_BOUND_PRESSURE_CELL,
+                           PFV_MAT_BOUND_PRESSURE_FACE, PFV_MAT_VECTOR_SOURCE,
+                           PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE};
+      for (int m : mats) {
+        if (m >= PFV_MAT_VECTOR_SOURCE && !with_vs) continue;
+        const int64_t nnz = h->pattern_of(m).nnz;
+        double* v = h->val[m].ensure(std::max<int64_t>(nnz, 1));
+        pfv::be_memset(v, 0, sizeof(double) * (size_t)nnz, s);
+      }
+    }
+    tm.start(s);
+    pfv::run_face_kernel(*h, with_vs, sub, n_faces);
+    h->stats.face_ms = tm.stop(s);
+    h->have_numeric = true;
+    h->have_system = false;
+    h->filled[PFV_MAT_SYSTEM] = false;
   });
 }
 

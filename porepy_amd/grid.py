@@ -386,3 +386,20 @@ def grid_to_raw(g) -> dict:
         "cell_volumes": np.ascontiguousarray(g.cell_volumes, dtype=np.float64),
         "fracture_faces": frac,
     }
+
+
+def grid_from_raw(raw: dict) -> Grid:
+    """Inverse of :func:`grid_to_raw`: a :class:`Grid` with the stored geometry (no recomputation)."""
+    nn = np.asarray(raw["nodes"]).shape[1]
+    nf = np.asarray(raw["face_centers"]).shape[1]
+    nc = np.asarray(raw["cell_centers"]).shape[1]
+    fn = sps.csc_matrix((np.ones(len(raw["fn_indices"]), dtype=bool), raw["fn_indices"], raw["fn_indptr"]),
+                        shape=(nn, nf))
+    cf = sps.csc_matrix((np.asarray(raw["cf_sign"]).astype(int), raw["cf_indices"], raw["cf_indptr"]),
+                        shape=(nf, nc))
+    g = Grid(int(raw["dim"]), raw["nodes"], fn, cf, str(raw.get("name", "")))
+    for k in ("face_normals", "face_centers", "cell_centers", "face_areas", "cell_volumes"):
+        setattr(g, k, np.asarray(raw[k], dtype=float))
+    if "fracture_faces" in raw:
+        g.tags["fracture_faces"] = np.asarray(raw["fracture_faces"], dtype=bool)
+    return g

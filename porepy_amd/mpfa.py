@@ -20,6 +20,7 @@ import numpy as np
 
 from . import _lib
 from .grid import grid_to_raw
+from .partial import active_indices
 from .params import DISCRETIZATION_MATRICES, PARAMETERS, bc_flags
 
 _KEYS = (
@@ -89,9 +90,9 @@ class Mpfa:
         vdim = pd.get("ambient_dimension", sd.dim)
         if vdim != sd.dim:
             raise NotImplementedError("ambient_dimension != grid dimension")
-        for unsupported in ("specified_cells", "specified_faces", "specified_nodes"):
-            if pd.get(unsupported) is not None:
-                raise NotImplementedError(f"partial discretization ({unsupported}) is not covered yet")
+        spec = [pd.get(k) for k in ("specified_cells", "specified_faces", "specified_nodes")]
+        partial = any(v is not None for v in spec)
+        update = bool(pd.get("update_discretization", False))
         if np.asarray(bnd.is_dir).size != sd.num_faces:
             raise NotImplementedError("boundary conditions on sub-faces are not covered yet")
         eta = pd.get("mpfa_eta", None)
@@ -104,8 +105,18 @@ class Mpfa:
         ctx = self.context(sd)
         ctx.set_params(np.asarray(k.values), bc_flags(bnd), np.asarray(bnd.robin_weight, dtype=float),
                        float(eta), eta_sub)
+        rows = None
         try:
-            ctx.discretize(rebuild_topology=bool(pd.get("hip_rebuild_topology", False)))
+            if partial:
+                # node-list launch: only the interaction regions around the active faces
+                # (mpfa.py:178-204; active sets as _fvutils.py:1260-1462)
+                active_cells, active_faces = active_indices(sd, *spec)
+                keep = update and ctx.has_discretization
+                ctx.discretize_faces(active_faces, keep_other_rows=keep)
+                rows = None if keep else active_faces
+            else:
+                ctx.discretize(rebuild_topology=bool(pd.get("hip_rebuild_topology", False)))
+                active_cells, active_faces = np.arange(sd.num_cells), np.arange(sd.num_faces)
         except _lib.PorefvError as e:
             if e.status == 1:  # same exception type and text as the reference
                 raise ValueError("Error in inversion of local linear systems") from e
@@ -113,14 +124,51 @@ class Mpfa:
                 raise AssertionError(e.message) from e
             raise
         for name, which in _KEYS:
-            md[name] = ctx.matrix(which)
+            new = ctx.matrix(which, rows=rows)
+            if partial and update and rows is not None and name in md:
+                # update without device history: splice the recomputed rows into the caller's
+                # matrices (mpfa.py:466-485)
+                old = md[name].tolil()
+                old[active_faces] = new[active_faces]
+                new = old.tocsr()
+            md[name] = new
         # side effect of the reference's find_active_indices (_fvutils.py:346-353)
-        pd["active_cells"] = np.arange(sd.num_cells)
-        pd["active_faces"] = np.arange(sd.num_faces)
+        pd["active_cells"] = active_cells
+        pd["active_faces"] = active_faces
 
     def update_discretization(self, sd, data: dict) -> None:
-        # full rediscretization; the node-list variant (mpfa.py:510-590) is a later row
-        self.discretize(sd, data)
+        """Rediscretize around ``data["update_discretization"]["modified_cells" / "modified_faces"]``
+        and keep every other row (mpfa.py:510-590 via _fvutils.partial_update_discretization,
+        _fvutils.py:1090-1257).  Renumbering maps (``map_cells`` / ``map_faces``: the grid itself
+        changed) lead to a full rediscretization of the new grid, which yields the same matrices."""
+        info = data.get("update_discretization", {})
+        pd = data[PARAMETERS][self.keyword]
+        cells = np.asarray(info.get("modified_cells", []), dtype=int)
+        faces = np.asarray(info.get("modified_faces", []), dtype=int)
+        ent = self._contexts.get(id(sd))
+        remapped = "map_cells" in info or "map_faces" in info
+        if remapped or ent is None or ent[0] is not sd or not ent[1].has_discretization:
+            saved = {k: pd.pop(k, None) for k in ("specified_cells", "specified_faces", "specified_nodes")}
+            pd["hip_rebuild_topology"] = True
+            try:
+                self.discretize(sd, data)
+            finally:
+                pd.pop("hip_rebuild_topology", None)
+                pd.update({k: v for k, v in saved.items() if v is not None})
+            return
+        if cells.size == 0 and faces.size == 0:
+            return
+        # the reference leaves these in the parameter dictionary (_fvutils.py:1175-1180)
+        if cells.size:
+            pd["specified_cells"] = cells
+        if faces.size:
+            pd["specified_faces"] = faces
+        was = pd.get("update_discretization", False)
+        pd["update_discretization"] = True
+        try:
+            self.discretize(sd, data)
+        finally:
+            pd["update_discretization"] = was
 
     def assemble_matrix_rhs(self, sd, data: dict):
         """(A, b) with A = div @ flux and b = -div @ bound_flux @ bc_values
@@ -170,6 +218,11 @@ def as_porepy_discretization(device: int = 0, library=None):
             if sd.dim < 2:
                 return super().discretize(sd, data)  # 1-D -> Tpfa, 0-D -> empty, as upstream
             return self._hip.discretize(sd, data)
+
+        def update_discretization(self, sd, data):
+            if sd.dim < 2:
+                return super().update_discretization(sd, data)
+            return self._hip.update_discretization(sd, data)
 
         def assemble_matrix_rhs(self, sd, data):
             if sd.dim < 2:

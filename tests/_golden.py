@@ -20,7 +20,7 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers" and not n.startswith("mpsa_")]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "partial_"))]
 
 
 def mpsa_case_names():
@@ -117,3 +117,36 @@ def check_pattern(ours, ref, tol=1e-12):
             denom = rowmax[r] if rowmax[r] > 0 else gmax
             worst = max(worst, abs(v) / denom)
     return subset, worst, po == pr
+
+
+class PartialCase:
+    """Partial-discretization / update fixture made by oracle/gen_golden_partial.py."""
+
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.grid["name"] = str(self.grid["name"])
+        self.bc = {k[3:]: z[k] for k in z.files if k.startswith("bc_")}
+        self.perm, self.perm_new = z["perm"], z["perm_new"]
+        self.modified_cells = z["modified_cells"]
+
+        def mats(prefix):
+            out = {}
+            for k in ALL_KEYS:
+                shape = tuple(int(v) for v in z[f"{prefix}_{k}_shape"])
+                out[k] = sps.csr_matrix((z[f"{prefix}_{k}_data"], z[f"{prefix}_{k}_indices"],
+                                         z[f"{prefix}_{k}_indptr"]), shape=shape)
+            return out
+
+        self.partial = []
+        for i in range(int(z["num_partial"])):
+            spec = {}
+            for kind in ("cells", "faces", "nodes"):
+                v = z[f"p{i}_spec_{kind}"]
+                if not (v.size == 1 and v[0] == -1):
+                    spec["specified_" + kind] = v
+            self.partial.append({"spec": spec, "active_faces": z[f"p{i}_active_faces"],
+                                 "active_cells": z[f"p{i}_active_cells"], "mats": mats(f"p{i}")})
+        self.updated = mats("upd")

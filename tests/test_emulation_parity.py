@@ -141,3 +141,12 @@ def test_rediscretize_with_new_parameters_reuses_topology(lib):
     f_new = data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"]
     assert abs(f_new - f_old).max() > 1e-3
     assert d.context(g).stats()["num_sub_half_faces"] == st1["num_sub_half_faces"]
+
+
+@pytest.mark.parametrize("name", ["partial_cart2d_5x5", "partial_tet3d_3x3x3"])
+def test_partial_discretization_and_update(lib, name):
+    P.check_partial_case(lib, name)
+
+
+def test_partial_discretization_one_cell_at_a_time(lib):
+    P.partial_one_cell_at_a_time(lib)

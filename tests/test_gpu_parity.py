@@ -90,3 +90,46 @@ def test_tutorial_sum_and_config_c1(lib):
 def test_error_behaviour(lib):
     from tests.test_emulation_parity import test_error_behaviour_matches_reference as body
     body(lib)
+
+
+@pytest.mark.parametrize("name", ["partial_cart2d_5x5", "partial_tet3d_3x3x3"])
+def test_partial_discretization_and_update(lib, name):
+    P.check_partial_case(lib, name)
+
+
+def test_partial_discretization_one_cell_at_a_time(lib):
+    P.partial_one_cell_at_a_time(lib)
+
+
+def test_update_at_scale_touches_only_active_rows(lib):
+    """~200 k tetrahedra: new permeability in 50 cells, update on the device, compare with a
+    fresh discretization (every row) and check the untouched rows are bit-identical."""
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([32, 32, 32], [1, 1, 1])), 0.008)
+    rng = np.random.default_rng(5)
+    k = 1 + rng.random(g.num_cells)
+    K = pa.SecondOrderTensor(kxx=k, kyy=2 * k, kzz=0.5 * k, kxy=0.2 * k)
+    bf = g.get_all_boundary_faces()
+    bc = pa.BoundaryCondition(g, bf, ["dir"] * bf.size)
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc})
+    d = pa.Mpfa("flow", library=lib)
+    d.discretize(g, data)
+    old = data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"].copy()
+    cells = rng.choice(g.num_cells, 50, replace=False)
+    k2 = k.copy()
+    k2[cells] *= 20.0
+    K2 = pa.SecondOrderTensor(kxx=k2, kyy=2 * k2, kzz=0.5 * k2, kxy=0.2 * k2)
+    data[pa.PARAMETERS]["flow"]["second_order_tensor"] = K2
+    data["update_discretization"] = {"modified_cells": cells}
+    d.update_discretization(g, data)
+    fresh = pa.initialize_data({}, "flow", {"second_order_tensor": K2, "bc": bc})
+    pa.Mpfa("flow", library=lib).discretize(g, fresh)
+    for key in ("flux", "bound_flux", "vector_source"):
+        a = data[pa.DISCRETIZATION_MATRICES]["flow"][key]
+        b = fresh[pa.DISCRETIZATION_MATRICES]["flow"][key]
+        assert np.array_equal(a.indices, b.indices)
+        assert abs(a.data - b.data).max() <= 1e-12 * abs(b.data).max(), key
+    _, touched = pa.active_indices(g, cells=cells)
+    untouched = np.setdiff1d(np.arange(g.num_faces), touched)
+    new = data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"]
+    assert np.array_equal(new[untouched].data, old[untouched].data)
+    assert touched.size < 0.05 * g.num_faces
