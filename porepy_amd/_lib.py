@@ -320,13 +320,15 @@ class Context:
         self._check(self.lib.pfv_spmv(self._h, which, _ptr(x, _dp), _ptr(y, _dp)))
         return y
 
-    def solve(self, method="bicgstab", rtol=1e-12, maxit=10000, x0=None, raise_on_fail=True, n=None):
-        """Solve the system assembled last (flow: n = Nc; mechanics: pass n = nd * Nc)."""
-        code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB}[method]
+    def solve(self, method="bicgstab", rtol=1e-12, maxit=10000, x0=None, raise_on_fail=True, n=None,
+              restart=0):
+        """Solve the system assembled last (flow: n = Nc; mechanics: pass n = nd * Nc).
+        ``restart``: GMRES cycle length (0 = 30)."""
+        code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB, "gmres": SOLVE_GMRES}[method]
         x = np.empty(self.nc if n is None else int(n), dtype=np.float64)
         x0a = None if x0 is None else _f64(x0)
         info = SolveInfo()
-        st = self.lib.pfv_solve(self._h, code, float(rtol), int(maxit), 0, _ptr(x0a, _dp), _ptr(x, _dp),
+        st = self.lib.pfv_solve(self._h, code, float(rtol), int(maxit), int(restart), _ptr(x0a, _dp), _ptr(x, _dp),
                                 C.byref(info))
         out = {"iterations": info.iterations, "converged": bool(info.converged),
                "rel_residual": info.rel_residual, "solve_ms": info.solve_ms}

@@ -110,6 +110,7 @@ struct pfv_ctx_impl {
   Buf<double> rhs, diag, xsol, face_tmp, vec_in;
   Buf<double> kry[10];
   Buf<double> red;  // reduction partials
+  Buf<double> gmres_basis, gmres_small;  // Arnoldi basis [(m+1) n]; Hessenberg / rotations / scalars
 
   // ---- MPSA -------------------------------------------------------------------------
   bool have_mpsa_params = false, have_mpsa_numeric = false, have_mpsa_symbolic = false, have_mech_system = false;

@@ -480,13 +480,12 @@ pfv_status pfv_sync(pfv_ctx* h) {
 
 pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart, const double* x0,
                      double* x, pfv_solve_info* info) {
-  (void)restart;
   pfv::SolveResult res;
   pfv_status st = guarded(h, [&] {
     require(h->active.valid, "assemble first");
     require(x != nullptr, "x is required");
-    require(method == PFV_SOLVE_CG || method == PFV_SOLVE_BICGSTAB,
-            "method must be PFV_SOLVE_CG or PFV_SOLVE_BICGSTAB");
+    require(method == PFV_SOLVE_CG || method == PFV_SOLVE_BICGSTAB || method == PFV_SOLVE_GMRES,
+            "method must be PFV_SOLVE_CG, PFV_SOLVE_BICGSTAB or PFV_SOLVE_GMRES");
     require(rtol > 0 && maxit > 0, "rtol and maxit must be positive");
     auto s = h->stream;
     const size_t n = (size_t)h->active.n;
@@ -494,7 +493,8 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
     if (x0) be_h2d(dx, x0, n * sizeof(double), s); else pfv::be_memset(dx, 0, n * sizeof(double), s);
     pfv::Timer tm;
     tm.start(s);
-    res = pfv::krylov_solve(*h, h->active, method, rtol, maxit, dx, x0 == nullptr);
+    res = method == PFV_SOLVE_GMRES ? pfv::gmres_solve(*h, h->active, rtol, maxit, restart, dx, x0 == nullptr)
+                                    : pfv::krylov_solve(*h, h->active, method, rtol, maxit, dx, x0 == nullptr);
     h->stats.solve_ms = tm.stop(s);
     be_d2h(x, dx, n * sizeof(double), s);
   });

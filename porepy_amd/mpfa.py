@@ -40,6 +40,21 @@ def determine_eta(sd) -> float:
     return 1.0 / 3.0 if ("TriangleGrid" in name or "TetrahedralGrid" in name) else 0.0
 
 
+def plane_basis(nodes: np.ndarray, tol: float = 1e-5):
+    """(2, 3) orthonormal basis of the plane holding the nodes of a 2-D grid, or None when the
+    grid already lies in a plane z = const (then the first two coordinates are used as is).
+    The role of ``map_geometry.project_plane_matrix`` (geometry/map_geometry.py:215-270); the
+    discretization does not depend on which in-plane basis is picked."""
+    x = np.asarray(nodes, dtype=float)
+    if np.ptp(x[2]) <= 1e-12 * max(1.0, np.ptp(x[0]), np.ptp(x[1])):
+        return None
+    xc = x - x.mean(axis=1, keepdims=True)
+    w, v = np.linalg.eigh(xc @ xc.T)  # ascending: v[:, 0] is the plane normal
+    if w[0] > (tol ** 2) * w[2] * x.shape[1]:
+        raise AssertionError("the nodes of a 2-D grid must be planar")
+    return np.ascontiguousarray(v[:, [2, 1]].T)
+
+
 class Mpfa:
     """MPFA-O flux discretization for ``keyword`` on the device."""
 
@@ -54,6 +69,7 @@ class Mpfa:
         self.vector_source_matrix_key = "vector_source"
         self.bound_pressure_vector_source_matrix_key = "bound_pressure_vector_source"
         self._contexts: dict = {}
+        self._plane: dict = {}  # id(sd) -> (2, 3) in-plane basis of a tilted 2-D grid, or None
 
     # ---- Discretization API ---------------------------------------------------------
     def ndof(self, sd) -> int:
@@ -76,10 +92,18 @@ class Mpfa:
             # matrices in 0-D (mpfa.py:129-149); neither is part of this hot path
             raise NotImplementedError("porepy_amd.Mpfa covers 2-D and 3-D grids")
         raw = grid_to_raw(sd)
-        if sd.dim == 2 and np.ptp(raw["nodes"][2]) > 1e-12 * max(1.0, np.ptp(raw["nodes"][:2])):
-            # the reference rotates embedded 2-D grids into the xy-plane first
-            # (mpfa.py:733-754 via map_geometry.map_grid)
-            raise NotImplementedError("2-D grids must lie in a plane z = const")
+        T = None
+        if sd.dim == 2:
+            # 2-D grids embedded in 3-D are discretized in local in-plane coordinates
+            # (mpfa.py:733-754 via map_geometry.map_grid); any orthonormal in-plane basis
+            # gives the same matrices once the vector source is mapped back
+            T = plane_basis(raw["nodes"])
+            if T is not None:
+                for k in ("nodes", "face_normals", "face_centers", "cell_centers"):
+                    loc = np.zeros_like(raw[k])
+                    loc[:2] = T @ raw[k]
+                    raw[k] = loc
+        self._plane[id(sd)] = T
         ctx.set_grid(raw)
 
     def discretize(self, sd, data: dict) -> None:
@@ -88,8 +112,8 @@ class Mpfa:
         k = pd["second_order_tensor"]
         bnd = pd["bc"]
         vdim = pd.get("ambient_dimension", sd.dim)
-        if vdim != sd.dim:
-            raise NotImplementedError("ambient_dimension != grid dimension")
+        if vdim != sd.dim and not (sd.dim == 2 and vdim == 3):
+            raise NotImplementedError("ambient_dimension must be the grid dimension (or 3 for a 2-D grid)")
         spec = [pd.get(k) for k in ("specified_cells", "specified_faces", "specified_nodes")]
         partial = any(v is not None for v in spec)
         update = bool(pd.get("update_discretization", False))
@@ -103,7 +127,17 @@ class Mpfa:
             eta_sub = np.asarray(eta, dtype=float)
             eta = 0.0
         ctx = self.context(sd)
-        ctx.set_params(np.asarray(k.values), bc_flags(bnd), np.asarray(bnd.robin_weight, dtype=float),
+        T = self._plane.get(id(sd))
+        kval = np.asarray(k.values, dtype=float)
+        if T is not None:
+            if vdim != 3:
+                raise NotImplementedError("a 2-D grid outside the xy-plane needs ambient_dimension = 3")
+            # rotate the tensor into the plane (mpfa.py:748-754)
+            k2 = np.einsum("ia,abn,jb->ijn", T, kval, T)
+            kval = np.zeros_like(kval)
+            kval[:2, :2] = k2
+            kval[2, 2] = 1.0
+        ctx.set_params(kval, bc_flags(bnd), np.asarray(bnd.robin_weight, dtype=float),
                        float(eta), eta_sub)
         rows = None
         try:
@@ -123,8 +157,19 @@ class Mpfa:
             if e.status == 2:
                 raise AssertionError(e.message) from e
             raise
+        lift = None
+        if sd.dim == 2 and vdim == 3:
+            # vector sources live in the ambient space: append the map onto the plane of the
+            # grid, column block by column block (mpfa.py:422-463)
+            import scipy.sparse as sps
+
+            basis = T if T is not None else np.eye(2, 3)
+            lift = sps.kron(sps.identity(sd.num_cells, format="csr"), sps.csr_matrix(basis), format="csr")
         for name, which in _KEYS:
             new = ctx.matrix(which, rows=rows)
+            if lift is not None and "vector_source" in name:
+                new = (new @ lift).tocsr()
+                new.sort_indices()
             if partial and update and rows is not None and name in md:
                 # update without device history: splice the recomputed rows into the caller's
                 # matrices (mpfa.py:466-485)
@@ -179,22 +224,35 @@ class Mpfa:
         if ent is None or ent[0] is not sd:
             raise RuntimeError("discretize(sd, data) must run on this object before assemble_matrix_rhs")
         ctx = ent[1]
-        vs = pd.get("vector_source", None)
-        ctx.assemble(np.asarray(pd["bc_values"], dtype=float), vs, None)
+        ctx.assemble(np.asarray(pd["bc_values"], dtype=float), self._vector_source(sd, pd), None)
         return ctx.matrix(_lib.MAT_SYSTEM), ctx.rhs()
+
+    def _vector_source(self, sd, pd):
+        """Cell-wise vector source in the coordinates the device discretized in."""
+        vs = pd.get("vector_source", None)
+        if vs is None:
+            return None
+        vs = np.asarray(vs, dtype=float)
+        vdim = pd.get("ambient_dimension", sd.dim)
+        if sd.dim == 2 and vdim == 3:
+            T = self._plane.get(id(sd))
+            basis = T if T is not None else np.eye(2, 3)
+            vs = (vs.reshape(sd.num_cells, 3) @ basis.T).ravel()
+        return vs
 
     # ---- solve (stand-in for SolutionStrategy.solve_linear_system) --------------------
     def solve(self, sd, data: dict, source=None, method: str = "bicgstab", rtol: float = 1e-12,
-              maxit: int = 20000, x0=None):
-        """Solve A p = b + source with the Jacobi-preconditioned Krylov solver on the device,
-        re-using the device-resident system.  Returns (p, info)."""
+              maxit: int = 20000, x0=None, restart: int = 0):
+        """Solve A p = b + source with the Jacobi-preconditioned Krylov solver on the device
+        (method: "bicgstab", "gmres" (restart = cycle length) or "cg"), re-using the
+        device-resident system.  Returns (p, info)."""
         pd = data[PARAMETERS][self.keyword]
         ent = self._contexts.get(id(sd))
         if ent is None or ent[0] is not sd:
             raise RuntimeError("discretize(sd, data) must run on this object before solve")
         ctx = ent[1]
-        ctx.assemble(np.asarray(pd["bc_values"], dtype=float), pd.get("vector_source", None), source)
-        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0)
+        ctx.assemble(np.asarray(pd["bc_values"], dtype=float), self._vector_source(sd, pd), source)
+        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, restart=restart)
 
 
 def as_porepy_discretization(device: int = 0, library=None):

@@ -104,6 +104,7 @@ class Mpsa:
         n = sd.dim * sd.num_cells
         return ctx.matrix(_lib.MAT_MECH_SYSTEM), ctx.active_rhs(n)
 
-    def solve(self, sd, data: dict, method: str = "bicgstab", rtol: float = 1e-12, maxit: int = 50000, x0=None):
+    def solve(self, sd, data: dict, method: str = "bicgstab", rtol: float = 1e-12, maxit: int = 50000, x0=None,
+              restart: int = 0):
         ctx = self._assemble(sd, data)
-        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, n=sd.dim * sd.num_cells)
+        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, n=sd.dim * sd.num_cells, restart=restart)

@@ -20,7 +20,7 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "partial_"))]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "partial_", "tilted_"))]
 
 
 def mpsa_case_names():
@@ -150,3 +150,23 @@ class PartialCase:
             self.partial.append({"spec": spec, "active_faces": z[f"p{i}_active_faces"],
                                  "active_cells": z[f"p{i}_active_cells"], "mats": mats(f"p{i}")})
         self.updated = mats("upd")
+
+
+class TiltedCase:
+    """2-D grid embedded in 3-D, ambient_dimension = 3 (oracle/gen_golden_tilted.py)."""
+
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.grid["name"] = str(self.grid["name"])
+        self.bc = {k[3:]: z[k] for k in z.files if k.startswith("bc_") and k != "bc_values"}
+        self.perm, self.bc_values = z["perm"], z["bc_values"]
+        self.vector_source_values = z["vector_source_values"]
+        self.ref = {}
+        for k in ALL_KEYS + ("A",):
+            shape = tuple(int(v) for v in z[f"ref_{k}_shape"])
+            self.ref[k] = sps.csr_matrix((z[f"ref_{k}_data"], z[f"ref_{k}_indices"], z[f"ref_{k}_indptr"]),
+                                         shape=shape)
+        self.ref_rhs = z["ref_rhs"]

@@ -11,7 +11,7 @@ import scipy.sparse.linalg as spla
 
 import porepy_amd as pa
 from oracle import mpfa_oracle as mo
-from tests._golden import ALL_KEYS, Case, PartialCase, check_pattern, rel_max_err
+from tests._golden import ALL_KEYS, Case, PartialCase, TiltedCase, check_pattern, rel_max_err
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMUL_SO = os.path.join(ROOT, "oracle", "_build", "libporefv_emul.so")
@@ -192,6 +192,25 @@ def check_partial_case(lib, name: str):
                           full_m["flux"][untouched].data)
 
 
+def check_tilted_case(lib, name: str):
+    """2-D grid rotated out of the xy-plane, full 3-D permeability, 3-D vector source:
+    every matrix, A and b against the reference (mpfa.py:733-754, 422-463)."""
+    c = TiltedCase(name)
+    g = pa.grid_from_raw(c.grid)
+    K = type("K", (), {"values": c.perm})()
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": _RawBC(c.bc), "bc_values": c.bc_values,
+                                           "ambient_dimension": 3, "vector_source": c.vector_source_values})
+    d = pa.Mpfa("flow", library=lib)
+    d.discretize(g, data)
+    for k in ALL_KEYS:
+        M = data[pa.DISCRETIZATION_MATRICES]["flow"][k]
+        assert M.shape == c.ref[k].shape, (name, k)
+        assert rel_max_err(M, c.ref[k]) < TOL, (name, k)
+    A, b = d.assemble_matrix_rhs(g, data)
+    assert rel_max_err(A, c.ref["A"]) < TOL
+    assert np.linalg.norm(b - c.ref_rhs) <= TOL * np.linalg.norm(c.ref_rhs)
+
+
 def partial_one_cell_at_a_time(lib):
     """Gradual build: discretize the nodes of one cell at a time and sum the pieces
     (tests/numerics/fv/test_mpfa.py:574-640)."""
@@ -223,6 +242,34 @@ def partial_one_cell_at_a_time(lib):
     pa.Mpfa("flow", library=lib).discretize(g, data)
     for k in keys:
         assert rel_max_err(acc[k], data[pa.DISCRETIZATION_MATRICES]["flow"][k]) < TOL, k
+
+
+def gmres_matches_direct(lib, g, restart=0, seed=1):
+    """Jacobi-GMRES(m) on the (non-symmetric) MPFA system against a direct solve of the same system;
+    a warm start from the solution must return immediately."""
+    rng = np.random.default_rng(seed)
+    nc = g.num_cells
+    K = pa.SecondOrderTensor(kxx=1 + rng.random(nc), kyy=3 + rng.random(nc), kxy=0.5 * rng.random(nc),
+                             **({"kzz": 0.4 + rng.random(nc), "kyz": 0.2 * rng.random(nc)} if g.dim == 3 else {}))
+    bf = g.get_all_boundary_faces()
+    bc = pa.BoundaryCondition(g, bf, list(np.array(["dir", "neu", "dir", "rob"])[np.arange(bf.size) % 4]))
+    bv = np.zeros(g.num_faces)
+    bv[bf] = rng.random(bf.size)
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": bv})
+    d = pa.Mpfa("flow", library=lib)
+    d.discretize(g, data)
+    A, b = d.assemble_matrix_rhs(g, data)
+    src = rng.random(nc) * g.cell_volumes
+    xo = spla.spsolve(A.tocsc(), b + src)
+    x, info = d.solve(g, data, source=src, method="gmres", rtol=1e-13, restart=restart, maxit=5000)
+    assert info["converged"] and info["iterations"] > 1
+    assert np.linalg.norm(b + src - A @ x) <= 1e-12 * np.linalg.norm(b + src)
+    assert np.linalg.norm(x - xo) <= TOL * np.linalg.norm(xo)
+    xb, ib = d.solve(g, data, source=src, method="bicgstab", rtol=1e-13)
+    assert np.linalg.norm(x - xb) <= TOL * np.linalg.norm(xo)
+    x2, info2 = d.solve(g, data, source=src, method="gmres", rtol=1e-9, x0=x)
+    assert info2["iterations"] == 0 and info2["converged"]
+    return info
 
 
 def linear_field_exact(lib, g, tol=1e-11):

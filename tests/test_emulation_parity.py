@@ -150,3 +150,16 @@ def test_partial_discretization_and_update(lib, name):
 
 def test_partial_discretization_one_cell_at_a_time(lib):
     P.partial_one_cell_at_a_time(lib)
+
+
+@pytest.mark.parametrize("name", ["tilted_cart2d_4x3", "tilted_tri2d_4x4", "tilted_flat_tri2d_3x3"])
+def test_2d_grid_embedded_in_3d(lib, name):
+    P.check_tilted_case(lib, name)
+
+
+@pytest.mark.parametrize("restart", [0, 7])
+def test_gmres(lib, restart):
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([4, 4, 4], [1, 1, 1])), 0.04)
+    P.gmres_matches_direct(lib, g, restart=restart)
+    g = _geo(pa.CartGrid([9, 7], [1, 1]))
+    P.gmres_matches_direct(lib, g, restart=restart)

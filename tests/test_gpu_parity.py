@@ -133,3 +133,16 @@ def test_update_at_scale_touches_only_active_rows(lib):
     new = data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"]
     assert np.array_equal(new[untouched].data, old[untouched].data)
     assert touched.size < 0.05 * g.num_faces
+
+
+@pytest.mark.parametrize("name", ["tilted_cart2d_4x3", "tilted_tri2d_4x4", "tilted_flat_tri2d_3x3"])
+def test_2d_grid_embedded_in_3d(lib, name):
+    P.check_tilted_case(lib, name)
+
+
+@pytest.mark.parametrize("restart", [0, 7])
+def test_gmres(lib, restart):
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([8, 8, 8], [1, 1, 1])), 0.02)
+    P.gmres_matches_direct(lib, g, restart=restart)
+    g = _geo(pa.CartGrid([9, 7], [1, 1]))
+    P.gmres_matches_direct(lib, g, restart=restart)
