@@ -311,6 +311,20 @@ inline void wave_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
 #endif
 }
 
+// wave_for with the lane-group width picked at run time (16 / 32 / 64): the one-item-per-wavefront
+// kernels are bound by the latency of their dependent index loads, so narrower groups (more items
+// in flight per wavefront) pay off whenever an item has fewer than ~64 parallel elements.
+template <class F>
+inline void wave_for_g(int G, stream_t s, int64_t n, size_t lds_bytes, F f) {
+  if (G <= 16) wave_for<16>(s, n, lds_bytes, f);
+  else if (G <= 32) wave_for<32>(s, n, lds_bytes, f);
+  else wave_for<64>(s, n, lds_bytes, f);
+}
+inline int env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
+}
+
 // T threads (several wavefronts) per work item, one item per workgroup: for work items whose LDS
 // footprint allows only one of them per CU anyway (MPSA interaction regions, ~140 KB).
 #ifndef PFV_EMULATE
