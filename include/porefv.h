@@ -53,7 +53,8 @@ enum {
   PFV_MAT_BOUND_DISPLACEMENT_CELL = 9,
   PFV_MAT_BOUND_DISPLACEMENT_FACE = 10,
   PFV_MAT_MECH_SYSTEM = 11,
-  PFV_NUM_MATS = 12
+  PFV_MAT_USER_SYSTEM = 12, /* matrix handed over by pfv_set_system */
+  PFV_NUM_MATS = 13
 };
 
 /* boundary-condition flag bits per face (params/bc.py:68-190: is_dir/is_neu/is_rob/
@@ -148,6 +149,15 @@ pfv_status pfv_get_rhs(pfv_ctx* h, double* b);
 
 /* y = M x for a produced matrix; host vectors (testing / flux post-processing) */
 pfv_status pfv_spmv(pfv_ctx* h, int which, const double* x, double* y);
+
+/* Hand an assembled system to the device solver: the caller of the hot path one level up,
+ * SolutionStrategy.solve_linear_system (models/solution_strategy.py:830-884), holds the global
+ * Jacobian as a scipy CSR matrix and the residual as a numpy vector.  CSR arrays (int32, any
+ * column order inside a row) and rhs are copied to the device; every row needs a non-zero
+ * diagonal entry (Jacobi preconditioner) or PFV_ERR_UNSUPPORTED is returned.  pfv_solve then
+ * operates on this system; needs no grid. */
+pfv_status pfv_set_system(pfv_ctx* h, int64_t n, const int32_t* indptr, const int32_t* indices,
+                          const double* data, const double* rhs);
 
 /* Jacobi-preconditioned Krylov solve of A x = b on the device (stand-in for
  * SolutionStrategy.solve_linear_system, models/solution_strategy.py:830-884).

@@ -12,6 +12,7 @@ from .grid import (CartGrid, Grid, StructuredTetrahedralGrid, StructuredTriangle
 from .mpfa import Mpfa, as_porepy_discretization, determine_eta
 from .mpsa import Mpsa
 from .partial import active_indices
+from .solvers import HipLinearSolver, solve_csr
 from .params import (DISCRETIZATION_MATRICES, PARAMETERS, BoundaryCondition, BoundaryConditionVectorial,
                      FourthOrderTensor, SecondOrderTensor, bc_flags, bc_to_raw, initialize_data)
 
@@ -20,5 +21,5 @@ __all__ = [
     "StructuredTetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "grid_from_raw", "Mpfa",
     "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition", "Mpsa",
     "FourthOrderTensor", "BoundaryConditionVectorial",
-    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices",
+    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr",
 ]

@@ -18,6 +18,7 @@ DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "libporefv_hip.so")
 MAT_FLUX, MAT_BOUND_FLUX, MAT_BOUND_PRESSURE_CELL, MAT_BOUND_PRESSURE_FACE = 0, 1, 2, 3
 MAT_VECTOR_SOURCE, MAT_BOUND_PRESSURE_VECTOR_SOURCE, MAT_SYSTEM = 4, 5, 6
 MAT_STRESS, MAT_BOUND_STRESS, MAT_BOUND_DISPLACEMENT_CELL, MAT_BOUND_DISPLACEMENT_FACE, MAT_MECH_SYSTEM = 7, 8, 9, 10, 11
+MAT_USER_SYSTEM = 12
 BC_DIR, BC_NEU, BC_ROB, BC_INTERNAL = 1, 2, 4, 8
 SOLVE_CG, SOLVE_BICGSTAB, SOLVE_GMRES = 0, 1, 2
 DISCR_REBUILD_TOPOLOGY, DISCR_SKIP_VECTOR_SOURCE = 1, 2
@@ -34,7 +35,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces",
+    "pfv_mpfa_discretize_faces", "pfv_set_system",
 ]
 
 
@@ -87,6 +88,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpfa_discretize.restype = C.c_int
     lib.pfv_mpfa_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int]
     lib.pfv_mpfa_discretize_faces.restype = C.c_int
+    lib.pfv_set_system.argtypes = [_h, C.c_int64, _ip, _ip, _dp, _dp]
+    lib.pfv_set_system.restype = C.c_int
     lib.pfv_matrix_info.argtypes = [_h, C.c_int, _lp, _lp, _lp]
     lib.pfv_matrix_info.restype = C.c_int
     lib.pfv_get_matrix.argtypes = [_h, C.c_int, _ip, _ip, _dp]
@@ -335,6 +338,23 @@ class Context:
         if st != 0 and (raise_on_fail or st != 6):
             self._check(st)
         return x, out
+
+    def set_system(self, A, b):
+        """Hand an assembled scipy CSR system to the device solver (no grid needed)."""
+        import scipy.sparse as sps
+
+        A = sps.csr_matrix(A)
+        n = A.shape[0]
+        if A.shape[0] != A.shape[1] or np.asarray(b).shape != (n,):
+            raise ValueError("square matrix and matching right-hand side expected")
+        if A.nnz >= 2 ** 31:
+            raise ValueError("more than 2^31 matrix entries")
+        ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        ix = np.ascontiguousarray(A.indices, dtype=np.int32)
+        dv = _f64(A.data)
+        bb = _f64(b)
+        self._check(self.lib.pfv_set_system(self._h, n, _ptr(ip, _ip), _ptr(ix, _ip), _ptr(dv, _dp), _ptr(bb, _dp)))
+        self._user_n = n
 
     def stats(self) -> dict:
         s = Stats()

@@ -106,7 +106,7 @@ struct pfv_ctx_impl {
   bool rows_complete = false;  // every row of the six MPFA matrices holds a discretization (maybe of older parameters)
   CsrPattern pat_flux, pat_bound, pat_vs, pat_A;  // bound_pressure_* share flux / bound patterns
   Buf<double> val[PFV_NUM_MATS];
-  bool filled[PFV_NUM_MATS] = {false, false, false, false, false, false, false, false, false, false, false, false};
+  bool filled[PFV_NUM_MATS] = {};
   Buf<double> rhs, diag, xsol, face_tmp, vec_in;
   Buf<double> kry[10];
   Buf<double> red;  // reduction partials
@@ -122,6 +122,8 @@ struct pfv_ctx_impl {
   Buf<int64_t> node_eptr, node_ebptr;  // [nn+1] offsets of the per-node expanded rows (cells / boundary faces)
   Buf<double> Es, Et, Esb, Etb;      // per node: (nd*nsf) x (nd*deg) stress / trace rows; x (nd*nb) boundary
   CsrPattern pat_stress, pat_bstress, pat_Am;
+  CsrPattern pat_user;               // pfv_set_system
+  Buf<double> rhs_u, diag_u;
   std::vector<int32_t> mpsa_class_lds;  // LDS bytes of the largest node per block-size class
   Buf<double> rhs_m, diag_m;
   LinSys active;                     // what pfv_solve / pfv_get_rhs operate on
@@ -147,6 +149,8 @@ struct pfv_ctx_impl {
         return pat_bstress;
       case PFV_MAT_MECH_SYSTEM:
         return pat_Am;
+      case PFV_MAT_USER_SYSTEM:
+        return pat_user;
       default:
         return pat_A;
     }

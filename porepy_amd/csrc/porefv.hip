@@ -264,7 +264,7 @@ pfv_status pfv_mpfa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces
 pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
-    require(which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic, "discretize first");
+    require(which == PFV_MAT_USER_SYSTEM ? h->filled[which] : (which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic), "discretize first");
     const pfv::CsrPattern& P = h->pattern_of(which);
     if (nrows) *nrows = P.nrows;
     if (ncols) *ncols = P.ncols;
@@ -275,7 +275,7 @@ pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols
 pfv_status pfv_get_matrix(pfv_ctx* h, int which, int32_t* indptr, int32_t* indices, double* data) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
-    require(which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic, "discretize first");
+    require(which == PFV_MAT_USER_SYSTEM ? h->filled[which] : (which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic), "discretize first");
     const pfv::CsrPattern& P = h->pattern_of(which);
     auto s = h->stream;
     if (indptr) be_d2h(indptr, P.indptr.p, sizeof(int32_t) * (size_t)(P.nrows + 1), s);
@@ -403,7 +403,7 @@ pfv_status pfv_get_rhs(pfv_ctx* h, double* b) {
 pfv_status pfv_spmv(pfv_ctx* h, int which, const double* x, double* y) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS && x && y, "bad argument");
-    require(h->have_symbolic && h->filled[which], "matrix values have not been computed");
+    require((h->have_symbolic || which == PFV_MAT_USER_SYSTEM) && h->filled[which], "matrix values have not been computed");
     const pfv::CsrPattern& P = h->pattern_of(which);
     auto s = h->stream;
     pfv::Buf<double> dx, dy;
@@ -418,7 +418,7 @@ pfv_status pfv_spmv(pfv_ctx* h, int which, const double* x, double* y) {
 pfv_status pfv_spmv_device(pfv_ctx* h, int which, const double* d_x, double* d_y) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS && d_x && d_y, "bad argument");
-    require(h->have_symbolic && h->filled[which], "matrix values have not been computed");
+    require((h->have_symbolic || which == PFV_MAT_USER_SYSTEM) && h->filled[which], "matrix values have not been computed");
     pfv::spmv(*h, h->pattern_of(which), h->val[which], d_x, d_y);
   });
 }
@@ -426,7 +426,7 @@ pfv_status pfv_spmv_device(pfv_ctx* h, int which, const double* d_x, double* d_y
 pfv_status pfv_spmv_device_rows(pfv_ctx* h, int which, int64_t nrows, const double* d_x, double* d_y) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS && d_x && d_y, "bad argument");
-    require(h->have_symbolic && h->filled[which], "matrix values have not been computed");
+    require((h->have_symbolic || which == PFV_MAT_USER_SYSTEM) && h->filled[which], "matrix values have not been computed");
     const pfv::CsrPattern& P = h->pattern_of(which);
     require(nrows >= 0 && nrows <= P.nrows, "nrows out of range");
     pfv::CsrPattern V;  // view of the leading rows (shares the index arrays)
@@ -476,6 +476,59 @@ pfv_status pfv_get_device_rhs(pfv_ctx* h, double** d_b, double** d_diag) {
 
 pfv_status pfv_sync(pfv_ctx* h) {
   return guarded(h, [&] { pfv::be_sync(h->stream); });
+}
+
+pfv_status pfv_set_system(pfv_ctx* h, int64_t n, const int32_t* indptr, const int32_t* indices,
+                          const double* data, const double* rhs) {
+  return guarded(h, [&] {
+    require(n > 0 && indptr && indices && data && rhs, "bad system");
+    require(indptr[0] == 0, "indptr must start at 0");
+    const int64_t nnz = indptr[n];
+    require(nnz >= 0, "bad indptr");
+    auto s = h->stream;
+    pfv::CsrPattern& P = h->pat_user;
+    P.nrows = P.ncols = n;
+    P.nnz = nnz;
+    int32_t* ip = P.indptr.ensure(n + 1);
+    int32_t* ix = P.indices.ensure(std::max<int64_t>(nnz, 1));
+    double* v = h->val[PFV_MAT_USER_SYSTEM].ensure(std::max<int64_t>(nnz, 1));
+    double* b = h->rhs_u.ensure(n);
+    double* dg = h->diag_u.ensure(n);
+    be_h2d(ip, indptr, sizeof(int32_t) * (size_t)(n + 1), s);
+    be_h2d(ix, indices, sizeof(int32_t) * (size_t)nnz, s);
+    be_h2d(v, data, sizeof(double) * (size_t)nnz, s);
+    be_h2d(b, rhs, sizeof(double) * (size_t)n, s);
+    int32_t* st = h->status.ensure(16);
+    pfv::be_memset(st, 0, sizeof(int32_t) * 4, s);
+    pfv::parallel_for(s, n, PFV_LAMBDA(int64_t i) {
+      double d = 0.0;
+      bool bad = false;
+      for (int e = ip[i]; e < ip[i + 1]; ++e) {
+        const int cidx = ix[e];
+        if (cidx < 0 || cidx >= n) bad = true;
+        else if (cidx == i) d += v[e];
+      }
+      dg[i] = d;
+      if (bad) pfv::atomic_max_i32(st + 1, 1);
+      if (!(d != 0.0) || !(d == d)) pfv::atomic_max_i32(st + 0, (int32_t)(i < 0x7fffffff ? i + 1 : 0x7fffffff));
+    });
+    int32_t sth[2];
+    be_d2h(sth, st, sizeof(sth), s);
+    require(!sth[1], "column index out of range");
+    if (sth[0])
+      throw pfv::Error(PFV_ERR_UNSUPPORTED, "zero diagonal entry in row " + std::to_string(sth[0] - 1) +
+                                                ": the Jacobi-preconditioned solver does not apply");
+    int mr = 0;
+    for (int64_t i = 0; i < n; ++i) mr = std::max(mr, indptr[i + 1] - indptr[i]);
+    P.max_row = mr;
+    h->filled[PFV_MAT_USER_SYSTEM] = true;
+    h->active.P = &P;
+    h->active.val = v;
+    h->active.diag = dg;
+    h->active.rhs = b;
+    h->active.n = n;
+    h->active.valid = true;
+  });
 }
 
 pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart, const double* x0,

@@ -43,15 +43,19 @@ class Model(Geometry, BCs, SinglePhaseFlow):
     pass
 
 
-def run():
-    params = {"times_to_export": [], "linear_solver": "scipy_sparse",
+class HipSolveModel(pa.HipLinearSolver, Model):
+    hip_library = P.emulation_library()
+
+
+def run(cls=Model, linear_solver="scipy_sparse"):
+    params = {"times_to_export": [], "linear_solver": linear_solver,
               "darcy_flux_discretization": "mpfa"}
-    m = Model(params)
+    m = cls(params)
     pp.run_time_dependent_model(m, params)
     sd = m.mdg.subdomains()[0]
     p = m.equation_system.get_variable_values([m.pressure_variable], time_step_index=0)
     A, b = m.linear_system
-    return sd.num_cells, np.asarray(p), A.copy(), np.asarray(b).copy()
+    return sd.num_cells, np.asarray(p), A.copy(), np.asarray(b).copy(), getattr(m, "hip_solver_info", None)
 
 
 ref = run()
@@ -68,7 +72,11 @@ def counting(self, sd, data):
 HipMpfa.discretize = counting
 pp.Mpfa = HipMpfa
 ours = run()
+# ... and with the linear solve routed to the device Krylov solver as well
+both = run(HipSolveModel, "hip_bicgstab")
 out = {
+    "p_rel_err_hip_solver": float(np.linalg.norm(both[1] - ref[1]) / np.linalg.norm(ref[1])),
+    "hip_solver_iterations": int(both[4]["iterations"]),
     "cells": int(ref[0]),
     "calls_into_device_path": calls["n"],
     "p_rel_err": float(np.linalg.norm(ours[1] - ref[1]) / np.linalg.norm(ref[1])),

@@ -146,3 +146,27 @@ def test_gmres(lib, restart):
     P.gmres_matches_direct(lib, g, restart=restart)
     g = _geo(pa.CartGrid([9, 7], [1, 1]))
     P.gmres_matches_direct(lib, g, restart=restart)
+
+
+def test_solver_for_assembled_csr_systems(lib):
+    """pfv_set_system: any CSR system with a non-zero diagonal (rows not sorted, no grid)."""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+
+    rng = np.random.default_rng(3)
+    n = 400
+    A = sps.random(n, n, density=0.02, random_state=5, format="csr") + sps.diags(4 + rng.random(n))
+    A = sps.csr_matrix(A)
+    perm = np.concatenate([rng.permutation(np.arange(A.indptr[i], A.indptr[i + 1])) for i in range(n)])
+    A = sps.csr_matrix((A.data[perm], A.indices[perm], A.indptr), shape=A.shape)  # unsorted columns
+    b = rng.random(n)
+    xo = spla.spsolve(A.tocsc(), b)
+    for method in ("bicgstab", "gmres"):
+        x, info = pa.solve_csr(A, b, method=method, rtol=1e-13, library=lib)
+        assert info["converged"]
+        assert np.linalg.norm(x - xo) <= 1e-10 * np.linalg.norm(xo), method
+    Z = A.tolil()
+    Z[7, 7] = 0.0
+    with pytest.raises(pa.PorefvError) as e:
+        pa.solve_csr(Z.tocsr(), b, library=lib)
+    assert e.value.status == 5 and "row 7" in e.value.message

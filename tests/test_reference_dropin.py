@@ -25,4 +25,5 @@ def test_single_phase_flow_model_with_rebound_mpfa():
     assert out["calls_into_device_path"] >= 1
     assert out["p_rel_err"] < 1e-10
     assert out["A_rel_err"] < 1e-10  # (the final residual vector is round-off in both runs)
+    assert out["p_rel_err_hip_solver"] < 1e-10 and out["hip_solver_iterations"] > 0
     assert abs(out["p_sum_ref"] - 8750.0) < 1e-6  # config C1 of the reference
