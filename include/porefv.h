@@ -121,6 +121,13 @@ pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t
 /* Mpfa._flux_discretization (numerics/fv/mpfa.py:592-1156) on the device. */
 pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags);
 
+/* Two-point flux approximation, Tpfa.discretize (numerics/fv/tpfa.py:84-279): what the
+ * reference's Mpfa delegates 1-D grids to (mpfa.py:690-712).  Uses the grid and the parameters
+ * of pfv_mpfa_set_params (eta and Robin weights are not used); works for nd = 1, 2, 3.  Fills
+ * matrices 0-5 with the patterns the reference stores (cell_faces pattern, diagonals);
+ * vector_source_dim = ``ambient_dimension`` (number of vector-source components per cell). */
+pfv_status pfv_tpfa_discretize(pfv_ctx* h, int vector_source_dim);
+
 /* Partial (re)discretization: the node-list launch behind ``specified_cells / _faces /
  * _nodes`` (numerics/fv/mpfa.py:178-204, 466-508) and ``update_discretization``
  * (mpfa.py:510-590, _fvutils.py:1090-1257).  ``faces`` = the faces whose rows are to be

@@ -13,6 +13,7 @@ from .mpfa import Mpfa, as_porepy_discretization, determine_eta
 from .mpsa import Mpsa
 from .partial import active_indices
 from .solvers import HipLinearSolver, solve_csr
+from .tpfa import Tpfa
 from .params import (DISCRETIZATION_MATRICES, PARAMETERS, BoundaryCondition, BoundaryConditionVectorial,
                      FourthOrderTensor, SecondOrderTensor, bc_flags, bc_to_raw, initialize_data)
 
@@ -21,5 +22,5 @@ __all__ = [
     "StructuredTetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "grid_from_raw", "Mpfa",
     "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition", "Mpsa",
     "FourthOrderTensor", "BoundaryConditionVectorial",
-    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr",
+    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa",
 ]

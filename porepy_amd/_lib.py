@@ -35,7 +35,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize",
 ]
 
 
@@ -88,6 +88,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpfa_discretize.restype = C.c_int
     lib.pfv_mpfa_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int]
     lib.pfv_mpfa_discretize_faces.restype = C.c_int
+    lib.pfv_tpfa_discretize.argtypes = [_h, C.c_int]
+    lib.pfv_tpfa_discretize.restype = C.c_int
     lib.pfv_set_system.argtypes = [_h, C.c_int64, _ip, _ip, _dp, _dp]
     lib.pfv_set_system.restype = C.c_int
     lib.pfv_matrix_info.argtypes = [_h, C.c_int, _lp, _lp, _lp]
@@ -264,6 +266,11 @@ class Context:
         self._check(self.lib.pfv_mpfa_discretize(self._h, flags))
         self._discretized = True
 
+    def tpfa_discretize(self, vector_source_dim: int):
+        self._check(self.lib.pfv_tpfa_discretize(self._h, int(vector_source_dim)))
+        self._discretized = False
+        self._vs_dim = int(vector_source_dim)
+
     @property
     def has_discretization(self) -> bool:
         return self._discretized
@@ -306,7 +313,11 @@ class Context:
         if bcv.shape != (self.nf,):
             raise ValueError("bc_values must have one entry per face")
         vs = None if vector_source is None else _f64(vector_source)
+        if vs is not None and vs.shape != (self.matrix_info(MAT_VECTOR_SOURCE)[1],):
+            raise ValueError("vector_source must have one entry per column of the vector_source matrix")
         src = None if source is None else _f64(source)
+        if src is not None and src.shape != (self.nc,):
+            raise ValueError("source must have one entry per cell")
         self._check(self.lib.pfv_mpfa_assemble(self._h, _ptr(bcv, _dp), _ptr(vs, _dp), _ptr(src, _dp)))
 
     def rhs(self):

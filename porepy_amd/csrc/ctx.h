@@ -123,6 +123,8 @@ struct pfv_ctx_impl {
   Buf<double> Es, Et, Esb, Etb;      // per node: (nd*nsf) x (nd*deg) stress / trace rows; x (nd*nb) boundary
   CsrPattern pat_stress, pat_bstress, pat_Am;
   CsrPattern pat_user;               // pfv_set_system
+  CsrPattern pat_bpf;                // TPFA: bound_pressure_face (diagonal of the Dirichlet / Neumann faces)
+  bool tpfa_mode = false;            // matrices 0-5 hold a TPFA discretization
   Buf<double> rhs_u, diag_u;
   std::vector<int32_t> mpsa_class_lds;  // LDS bytes of the largest node per block-size class
   Buf<double> rhs_m, diag_m;
@@ -135,8 +137,9 @@ struct pfv_ctx_impl {
       case PFV_MAT_FLUX:
       case PFV_MAT_BOUND_PRESSURE_CELL:
         return pat_flux;
-      case PFV_MAT_BOUND_FLUX:
       case PFV_MAT_BOUND_PRESSURE_FACE:
+        return tpfa_mode ? pat_bpf : pat_bound;
+      case PFV_MAT_BOUND_FLUX:
         return pat_bound;
       case PFV_MAT_VECTOR_SOURCE:
       case PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE:

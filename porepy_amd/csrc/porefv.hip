@@ -10,6 +10,7 @@
 #include "mpfa_numeric.inc"
 #include "linalg.inc"
 #include "mpsa.inc"
+#include "tpfa.inc"
 
 using pfv::be_d2h;
 using pfv::be_h2d;
@@ -110,7 +111,7 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
                         const double* face_normals, const double* face_centers,
                         const double* cell_centers, const double* face_areas) {
   return guarded(h, [&] {
-    require(nd == 2 || nd == 3, "nd must be 2 or 3 (1-D grids use TPFA in the reference, mpfa.py:690-712)");
+    require(nd >= 1 && nd <= 3, "nd must be 1, 2 or 3 (1-D grids: TPFA only, as in the reference, mpfa.py:690-712)");
     require(nc > 0 && nf > 0 && nn > 0, "empty grid");
     require(nodes && cf_indptr && cf_indices && cf_sign && fn_indptr && fn_indices && face_normals &&
                 face_centers && cell_centers && face_areas,
@@ -147,6 +148,7 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     h->have_grid = true;
     h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
     h->rows_complete = false;
+    h->tpfa_mode = false;
     h->have_mpsa_numeric = h->have_mpsa_symbolic = h->have_mech_system = false;
     h->active.valid = false;
     for (bool& f : h->filled) f = false;
@@ -178,15 +180,17 @@ pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t
 pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
   return guarded(h, [&] {
     require(h->have_grid && h->have_params, "grid and parameters must be set before discretize");
+    require(h->nd >= 2, "MPFA needs a 2-D or 3-D grid (1-D: pfv_tpfa_discretize)");
     auto s = h->stream;
     pfv::Timer tm;
-    if (!h->have_topology || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
+    if (!h->have_topology || !h->have_symbolic || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
       tm.start(s);
       pfv::build_topology(*h);
       h->stats.topology_ms = tm.stop(s);
       tm.start(s);
       pfv::build_symbolic(*h);
       h->stats.symbolic_ms = tm.stop(s);
+      h->tpfa_mode = false;
     }
     tm.start(s);
     pfv::run_node_kernel(*h);
@@ -206,19 +210,40 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
   });
 }
 
+pfv_status pfv_tpfa_discretize(pfv_ctx* h, int vector_source_dim) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_params, "grid and parameters must be set before discretize");
+    require(vector_source_dim >= 1 && vector_source_dim <= 3, "vector_source_dim must be 1, 2 or 3");
+    auto s = h->stream;
+    pfv::Timer tm;
+    tm.start(s);
+    h->have_symbolic = false;  // the MPFA patterns (if any) are replaced
+    h->rows_complete = false;
+    pfv::tpfa_discretize(*h, vector_source_dim);
+    h->stats.face_ms = tm.stop(s);
+    h->tpfa_mode = true;
+    h->have_symbolic = true;
+    h->have_topology = false;  // an MPFA call on this handle rebuilds its own topology + patterns
+    h->have_numeric = true;
+    h->have_system = false;
+  });
+}
+
 pfv_status pfv_mpfa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces, const int32_t* faces,
                                      int keep_other_rows) {
   return guarded(h, [&] {
     require(h->have_grid && h->have_params, "grid and parameters must be set before discretize");
     require(n_faces >= 0 && (n_faces == 0 || faces), "bad face list");
+    require(h->nd >= 2, "MPFA needs a 2-D or 3-D grid");
     require(!keep_other_rows || h->rows_complete,
             "update of a discretization that was never computed on this handle");
     for (int64_t i = 0; i < n_faces; ++i)
       require(faces[i] >= 0 && faces[i] < h->nf, "face index out of range");
     auto s = h->stream;
     pfv::Timer tm;
-    if (!h->have_topology || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
+    if (!h->have_topology || !h->have_symbolic || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
       require(!keep_other_rows, "the topology cannot be rebuilt under an update");
+      h->tpfa_mode = false;
       tm.start(s);
       pfv::build_topology(*h);
       h->stats.topology_ms = tm.stop(s);
@@ -296,12 +321,13 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     auto s = h->stream;
     pfv::Timer tm;
     const size_t nf = (size_t)h->nf, nc = (size_t)h->nc;
-    double* in = h->vec_in.ensure(nf + nc * (size_t)h->nd + nc);
+    const size_t nvs = (size_t)h->pat_vs.ncols;  // nd (MPFA) or ambient-dimension (TPFA) entries per cell
+    double* in = h->vec_in.ensure(nf + nvs + nc);
     double* d_bc = in;
     double* d_vs = vector_source ? in + nf : nullptr;
-    double* d_src = source ? in + nf + nc * (size_t)h->nd : nullptr;
+    double* d_src = source ? in + nf + nvs : nullptr;
     be_h2d(d_bc, bc_values, nf * sizeof(double), s);
-    if (d_vs) be_h2d(d_vs, vector_source, nc * (size_t)h->nd * sizeof(double), s);
+    if (d_vs) be_h2d(d_vs, vector_source, nvs * sizeof(double), s);
     if (d_src) be_h2d(d_src, source, nc * sizeof(double), s);
     tm.start(s);
     if (!h->have_system) pfv::assemble_system(*h);

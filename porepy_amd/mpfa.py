@@ -69,6 +69,7 @@ class Mpfa:
         self.vector_source_matrix_key = "vector_source"
         self.bound_pressure_vector_source_matrix_key = "bound_pressure_vector_source"
         self._contexts: dict = {}
+        self._tpfa_discr = None  # grids of dimension < 2
         self._plane: dict = {}  # id(sd) -> (2, 3) in-plane basis of a tilted 2-D grid, or None
 
     # ---- Discretization API ---------------------------------------------------------
@@ -87,10 +88,8 @@ class Mpfa:
         return ent[1]
 
     def _upload_grid(self, ctx, sd):
-        if sd.dim not in (2, 3):
-            # the reference hands 1-D grids to Tpfa (mpfa.py:690-712) and returns empty
-            # matrices in 0-D (mpfa.py:129-149); neither is part of this hot path
-            raise NotImplementedError("porepy_amd.Mpfa covers 2-D and 3-D grids")
+        if hasattr(sd, "periodic_face_map"):
+            raise NotImplementedError("periodic faces are not covered")
         raw = grid_to_raw(sd)
         T = None
         if sd.dim == 2:
@@ -106,7 +105,22 @@ class Mpfa:
         self._plane[id(sd)] = T
         ctx.set_grid(raw)
 
+    def _tpfa(self):
+        if self._tpfa_discr is None:
+            from .tpfa import Tpfa
+
+            self._tpfa_discr = Tpfa(self.keyword, self.device, self._library)
+        return self._tpfa_discr
+
     def discretize(self, sd, data: dict) -> None:
+        if sd.dim < 2:
+            # 1-D grids go to TPFA, 0-D grids get empty matrices (mpfa.py:690-723, 129-149); the
+            # reference's post-processing products drop the explicit zeros Tpfa stores (:360-372)
+            self._tpfa().discretize(sd, data)
+            md = data[DISCRETIZATION_MATRICES][self.keyword]
+            for name, _ in _KEYS:
+                md[name].eliminate_zeros()
+            return
         pd = data[PARAMETERS][self.keyword]
         md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
         k = pd["second_order_tensor"]
@@ -186,6 +200,8 @@ class Mpfa:
         and keep every other row (mpfa.py:510-590 via _fvutils.partial_update_discretization,
         _fvutils.py:1090-1257).  Renumbering maps (``map_cells`` / ``map_faces``: the grid itself
         changed) lead to a full rediscretization of the new grid, which yields the same matrices."""
+        if sd.dim < 2:
+            return self._tpfa().discretize(sd, data)
         info = data.get("update_discretization", {})
         pd = data[PARAMETERS][self.keyword]
         cells = np.asarray(info.get("modified_cells", []), dtype=int)
@@ -219,6 +235,8 @@ class Mpfa:
         """(A, b) with A = div @ flux and b = -div @ bound_flux @ bc_values
         (- div @ vector_source @ g), computed on the device from the device-resident
         discretization (fv_elliptic.py:67-112)."""
+        if sd.dim < 2:
+            return self._tpfa().assemble_matrix_rhs(sd, data)
         pd = data[PARAMETERS][self.keyword]
         ent = self._contexts.get(id(sd))
         if ent is None or ent[0] is not sd:
@@ -246,6 +264,9 @@ class Mpfa:
         """Solve A p = b + source with the Jacobi-preconditioned Krylov solver on the device
         (method: "bicgstab", "gmres" (restart = cycle length) or "cg"), re-using the
         device-resident system.  Returns (p, info)."""
+        if sd.dim < 2:
+            return self._tpfa().solve(sd, data, source=source, method=method, rtol=rtol, maxit=maxit, x0=x0,
+                                      restart=restart)
         pd = data[PARAMETERS][self.keyword]
         ent = self._contexts.get(id(sd))
         if ent is None or ent[0] is not sd:

@@ -20,7 +20,7 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "partial_", "tilted_"))]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "partial_", "tilted_", "tpfa_"))]
 
 
 def mpsa_case_names():
@@ -170,3 +170,5 @@ class TiltedCase:
             self.ref[k] = sps.csr_matrix((z[f"ref_{k}_data"], z[f"ref_{k}_indices"], z[f"ref_{k}_indptr"]),
                                          shape=shape)
         self.ref_rhs = z["ref_rhs"]
+        self.vdim = int(z["vdim"]) if "vdim" in z.files else 3
+        self.via_mpfa = bool(int(z["via_mpfa"])) if "via_mpfa" in z.files else False

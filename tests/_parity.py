@@ -211,6 +211,42 @@ def check_tilted_case(lib, name: str):
     assert np.linalg.norm(b - c.ref_rhs) <= TOL * np.linalg.norm(c.ref_rhs)
 
 
+def check_tpfa_case(lib, name: str):
+    """Tpfa (and Mpfa on 1-D grids, which delegates to it) against the reference: stored patterns
+    bit-exact, values, A and b (numerics/fv/tpfa.py:84-279, mpfa.py:690-712)."""
+    c = TiltedCase(name)  # same fixture layout
+    g = pa.grid_from_raw(c.grid)
+    K = type("K", (), {"values": c.perm})()
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": _RawBC(c.bc), "bc_values": c.bc_values,
+                                           "ambient_dimension": c.vdim, "vector_source": c.vector_source_values})
+    d = (pa.Mpfa if c.via_mpfa else pa.Tpfa)("flow", library=lib)
+    d.discretize(g, data)
+    for k in ALL_KEYS:
+        M = data[pa.DISCRETIZATION_MATRICES]["flow"][k]
+        R = c.ref[k]
+        assert M.shape == R.shape, (name, k)
+        assert np.array_equal(M.indptr, R.indptr) and np.array_equal(M.indices, R.indices), (name, k)
+        assert rel_max_err(M, R) < TOL, (name, k)
+    A, b = d.assemble_matrix_rhs(g, data)
+    assert rel_max_err(A, c.ref["A"]) < TOL
+    assert np.linalg.norm(b - c.ref_rhs) <= TOL * np.linalg.norm(c.ref_rhs)
+    src = np.ones(g.num_cells)
+    x, info = d.solve(g, data, source=src, method="bicgstab", rtol=1e-13)
+    xo = spla.spsolve(c.ref["A"].tocsc(), c.ref_rhs + src)
+    assert np.linalg.norm(x - xo) <= TOL * np.linalg.norm(xo)
+
+
+def check_zero_dimensional_grid(lib):
+    """0-D grids: empty matrices of the right shapes (mpfa.py:129-149)."""
+    g = type("Point", (), {"dim": 0, "num_cells": 1, "num_faces": 0, "num_nodes": 1})()
+    for cls in (pa.Mpfa, pa.Tpfa):
+        data = pa.initialize_data({}, "flow", {"ambient_dimension": 3})
+        cls("flow", library=lib).discretize(g, data)
+        m = data[pa.DISCRETIZATION_MATRICES]["flow"]
+        assert m["flux"].shape == (0, 1) and m["bound_flux"].shape == (0, 0)
+        assert m["vector_source"].shape == (0, 3) and m["bound_pressure_vector_source"].shape == (0, 3)
+
+
 def partial_one_cell_at_a_time(lib):
     """Gradual build: discretize the nodes of one cell at a time and sum the pieces
     (tests/numerics/fv/test_mpfa.py:574-640)."""

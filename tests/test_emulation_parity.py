@@ -187,3 +187,12 @@ def test_solver_for_assembled_csr_systems(lib):
     with pytest.raises(pa.PorefvError) as e:
         pa.solve_csr(Z.tocsr(), b, library=lib)
     assert e.value.status == 5 and "row 7" in e.value.message
+
+
+@pytest.mark.parametrize("name", ["tpfa_line_8", "tpfa_line_6_in_3d_via_mpfa", "tpfa_cart2d_4x3", "tpfa_tet3d_2x2x2"])
+def test_tpfa_and_1d_delegation(lib, name):
+    P.check_tpfa_case(lib, name)
+
+
+def test_zero_dimensional_grid(lib):
+    P.check_zero_dimensional_grid(lib)
