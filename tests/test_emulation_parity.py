@@ -124,11 +124,10 @@ def test_error_behaviour_matches_reference(lib):
     ctx = pa.Context(0, lib)
     with pytest.raises(pa.PorefvError):
         ctx.discretize()
-    # 1-D grids are not part of this path
-    class G1:
-        dim = 1
+    # periodic faces are refused, not silently ignored
+    g.periodic_face_map = np.array([[0], [3]])
     with pytest.raises(NotImplementedError):
-        pa.Mpfa("flow", library=lib)._upload_grid(ctx, G1())
+        pa.Mpfa("flow", library=lib).discretize(g, data)
 
 
 def test_rediscretize_with_new_parameters_reuses_topology(lib):
