@@ -182,6 +182,13 @@ pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const do
                                const uint8_t* bc_dir_bits, const uint8_t* bc_neu_bits, double eta);
 /* Mpsa._stress_discretization (numerics/fv/mpsa.py:531-782) on the device; fills matrices 7-10 */
 pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags);
+
+/* Partial MPSA (re)discretization, same contract as pfv_mpfa_discretize_faces
+ * (numerics/fv/mpsa.py:196-216, 383-416 and Mpsa.update_discretization :418-487): the
+ * interaction regions around the listed faces are re-solved, the nd rows of each listed face
+ * are rewritten in the four matrices, the other rows are zeroed (keep_other_rows = 0) or kept. */
+pfv_status pfv_mpsa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces,
+                                     const int32_t* faces, int keep_other_rows);
 /* Mpsa.assemble_matrix_rhs (mpsa.py:486-529): A = div_nd @ stress,
  * b = -div_nd @ bound_stress @ bc_values + source; bc_values has nd*Nf entries ((nd,Nf) raveled
  * column-major), source nd*Nc or NULL.  Makes the mechanics system the one pfv_solve works on

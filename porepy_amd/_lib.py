@@ -35,7 +35,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces",
 ]
 
 
@@ -88,6 +88,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpfa_discretize.restype = C.c_int
     lib.pfv_mpfa_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int]
     lib.pfv_mpfa_discretize_faces.restype = C.c_int
+    lib.pfv_mpsa_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int]
+    lib.pfv_mpsa_discretize_faces.restype = C.c_int
     lib.pfv_tpfa_discretize.argtypes = [_h, C.c_int]
     lib.pfv_tpfa_discretize.restype = C.c_int
     lib.pfv_set_system.argtypes = [_h, C.c_int64, _ip, _ip, _dp, _dp]
@@ -179,6 +181,7 @@ class Context:
                                   "(the product path has no CPU fallback)")
         self.nd = self.nc = self.nf = self.nn = 0
         self._discretized = False  # a complete MPFA discretization is resident on the device
+        self._discretized_m = False  # ... MPSA
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -198,6 +201,7 @@ class Context:
     # ---- inputs -------------------------------------------------------------------
     def set_grid(self, raw: dict):
         self._discretized = False
+        self._discretized_m = False
         nd = int(raw["dim"])
         nodes = _f64(raw["nodes"]); fn_ = _f64(raw["face_normals"]); fc = _f64(raw["face_centers"])
         cc = _f64(raw["cell_centers"]); fa = _f64(raw["face_areas"])
@@ -246,6 +250,17 @@ class Context:
 
     def mpsa_discretize(self, rebuild_topology=False):
         self._check(self.lib.pfv_mpsa_discretize(self._h, DISCR_REBUILD_TOPOLOGY if rebuild_topology else 0))
+        self._discretized_m = True
+
+    def mpsa_discretize_faces(self, faces, keep_other_rows: bool):
+        fa = np.ascontiguousarray(faces, dtype=np.int32)
+        self._check(self.lib.pfv_mpsa_discretize_faces(self._h, 0, fa.size, _ptr(fa, _ip),
+                                                       1 if keep_other_rows else 0))
+        self._discretized_m = self._discretized_m and bool(keep_other_rows)
+
+    @property
+    def has_mpsa_discretization(self) -> bool:
+        return self._discretized_m
 
     def mpsa_assemble(self, bc_values, source=None):
         bcv = _f64(bc_values)

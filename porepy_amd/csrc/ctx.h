@@ -124,6 +124,7 @@ struct pfv_ctx_impl {
   CsrPattern pat_stress, pat_bstress, pat_Am;
   CsrPattern pat_user;               // pfv_set_system
   CsrPattern pat_bpf;                // TPFA: bound_pressure_face (diagonal of the Dirichlet / Neumann faces)
+  bool rows_complete_m = false;      // every row of the four MPSA matrices holds a discretization
   bool tpfa_mode = false;            // matrices 0-5 hold a TPFA discretization
   Buf<double> rhs_u, diag_u;
   std::vector<int32_t> mpsa_class_lds;  // LDS bytes of the largest node per block-size class

@@ -148,6 +148,7 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     h->have_grid = true;
     h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
     h->rows_complete = false;
+    h->rows_complete_m = false;
     h->tpfa_mode = false;
     h->have_mpsa_numeric = h->have_mpsa_symbolic = h->have_mech_system = false;
     h->active.valid = false;
@@ -364,13 +365,14 @@ pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags) {
     require(h->have_grid && h->have_mpsa_params, "grid and MPSA parameters must be set before discretize");
     auto s = h->stream;
     pfv::Timer tm;
-    if (!h->have_topology || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
+    if (!h->have_topology || !h->have_symbolic || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
       tm.start(s);
       pfv::build_topology(*h);
       h->stats.topology_ms = tm.stop(s);
       tm.start(s);
       pfv::build_symbolic(*h);
       h->stats.symbolic_ms = tm.stop(s);
+      h->tpfa_mode = false;
       h->have_mpsa_symbolic = false;
       h->have_numeric = h->have_system = false;
     }
@@ -384,6 +386,57 @@ pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags) {
     h->stats.node_ms = tm.stop(s);
     tm.start(s);
     pfv::mpsa_run_face_kernel(*h);
+    h->stats.face_ms = tm.stop(s);
+    h->have_mpsa_numeric = true;
+    h->rows_complete_m = true;
+    h->have_mech_system = false;
+    h->filled[PFV_MAT_MECH_SYSTEM] = false;
+  });
+}
+
+pfv_status pfv_mpsa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces, const int32_t* faces,
+                                     int keep_other_rows) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_mpsa_params, "grid and MPSA parameters must be set before discretize");
+    require(n_faces >= 0 && (n_faces == 0 || faces), "bad face list");
+    require(!keep_other_rows || h->rows_complete_m,
+            "update of a discretization that was never computed on this handle");
+    for (int64_t i = 0; i < n_faces; ++i)
+      require(faces[i] >= 0 && faces[i] < h->nf, "face index out of range");
+    auto s = h->stream;
+    pfv::Timer tm;
+    if (!h->have_topology || !h->have_symbolic || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
+      require(!keep_other_rows, "the topology cannot be rebuilt under an update");
+      pfv::build_topology(*h);
+      pfv::build_symbolic(*h);
+      h->tpfa_mode = false;
+      h->have_mpsa_symbolic = false;
+      h->have_numeric = h->have_system = false;
+    }
+    if (!h->have_mpsa_symbolic) pfv::mpsa_symbolic(*h);
+    int32_t* sub = h->face_subset.ensure(std::max<int64_t>(n_faces, 1));
+    uint8_t* act = h->node_active.ensure(h->nn);
+    pfv::be_h2d(sub, faces, sizeof(int32_t) * (size_t)n_faces, s);
+    pfv::be_memset(act, 0, (size_t)h->nn, s);
+    const int32_t* fn_ptr = h->fn_ptr;
+    const int32_t* fn_idx = h->fn_idx;
+    pfv::parallel_for(s, n_faces, PFV_LAMBDA(int64_t i) {
+      const int f = sub[i];
+      for (int e = fn_ptr[f]; e < fn_ptr[f + 1]; ++e) act[fn_idx[e]] = 1;
+    });
+    tm.start(s);
+    pfv::mpsa_run_node_kernel(*h, act);
+    h->stats.node_ms = tm.stop(s);
+    if (!keep_other_rows) {
+      h->rows_complete_m = false;
+      for (int m = PFV_MAT_STRESS; m <= PFV_MAT_BOUND_DISPLACEMENT_FACE; ++m) {
+        const int64_t nnz = h->pattern_of(m).nnz;
+        double* v = h->val[m].ensure(std::max<int64_t>(nnz, 1));
+        pfv::be_memset(v, 0, sizeof(double) * (size_t)nnz, s);
+      }
+    }
+    tm.start(s);
+    pfv::mpsa_run_face_kernel(*h, sub, n_faces);
     h->stats.face_ms = tm.stop(s);
     h->have_mpsa_numeric = true;
     h->have_mech_system = false;

@@ -210,11 +210,11 @@ class Mpfa:
         remapped = "map_cells" in info or "map_faces" in info
         if remapped or ent is None or ent[0] is not sd or not ent[1].has_discretization:
             saved = {k: pd.pop(k, None) for k in ("specified_cells", "specified_faces", "specified_nodes")}
-            pd["hip_rebuild_topology"] = True
+            if remapped:
+                self._contexts.pop(id(sd), None)  # the grid itself changed: upload it again
             try:
                 self.discretize(sd, data)
             finally:
-                pd.pop("hip_rebuild_topology", None)
                 pd.update({k: v for k, v in saved.items() if v is not None})
             return
         if cells.size == 0 and faces.size == 0:

@@ -5,7 +5,7 @@ Operator API of ``pp.Mpsa`` (numerics/fv/mpsa.py:63-529): ``Mpsa(keyword)``, ``n
 parameters ``fourth_order_tensor``, ``bc`` (vectorial), ``bc_values`` ((nd, Nf) raveled "F"),
 ``source``, ``mpsa_eta``.  Unknown ordering is cell-major, component-minor (u[nd*c + a]).
 Covered: component-wise Dirichlet / Neumann conditions in the Cartesian basis.  Robin conditions,
-rotated bases, sub-face conditions and partial updates raise NotImplementedError.
+rotated bases and sub-face conditions raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -14,6 +14,7 @@ import numpy as np
 from . import _lib
 from .grid import grid_to_raw
 from .mpfa import determine_eta
+from .partial import active_indices
 from .params import DISCRETIZATION_MATRICES, PARAMETERS
 
 _KEYS = (
@@ -64,9 +65,9 @@ class Mpsa:
             eye = np.eye(sd.dim)[:, :, None]
             if not np.allclose(basis, eye):
                 raise NotImplementedError("rotated boundary bases are not covered yet")
-        for key in ("specified_cells", "specified_faces", "specified_nodes"):
-            if pd.get(key) is not None:
-                raise NotImplementedError(f"partial discretization ({key}) is not covered yet")
+        spec = [pd.get(k) for k in ("specified_cells", "specified_faces", "specified_nodes")]
+        partial = any(v is not None for v in spec)
+        update = bool(pd.get("update_discretization", False))
         eta = pd.get("mpsa_eta", None)
         if eta is None:
             eta = determine_eta(sd)
@@ -74,8 +75,18 @@ class Mpsa:
             raise NotImplementedError("per-sub-face eta is not covered for MPSA yet")
         ctx = self.context(sd)
         ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta))
+        rows = None
         try:
-            ctx.mpsa_discretize()
+            if partial:
+                # node-list launch around the active faces (mpsa.py:209-216, 383-416)
+                active_cells, active_faces = active_indices(sd, *spec)
+                keep = update and ctx.has_mpsa_discretization
+                ctx.mpsa_discretize_faces(active_faces, keep_other_rows=keep)
+                if not keep:
+                    rows = (sd.dim * active_faces[:, None] + np.arange(sd.dim)[None, :]).ravel()
+            else:
+                ctx.mpsa_discretize()
+                active_cells, active_faces = np.arange(sd.num_cells), np.arange(sd.num_faces)
         except _lib.PorefvError as e:
             if e.status == 1:
                 raise ValueError("Error in inversion of local linear systems") from e
@@ -83,10 +94,45 @@ class Mpsa:
                 raise AssertionError(e.message) from e
             raise
         for name, which in _KEYS:
-            md[name] = ctx.matrix(which)
+            new = ctx.matrix(which, rows=rows)
+            if partial and update and rows is not None and name in md:
+                old = md[name].tolil()
+                old[rows] = new[rows]
+                new = old.tocsr()
+            md[name] = new
+        pd["active_cells"] = active_cells
+        pd["active_faces"] = active_faces
 
     def update_discretization(self, sd, data: dict) -> None:
-        self.discretize(sd, data)
+        """Rediscretize around ``data["update_discretization"]["modified_cells" / "modified_faces"]``,
+        keep every other row (mpsa.py:418-487 via _fvutils.partial_update_discretization)."""
+        info = data.get("update_discretization", {})
+        pd = data[PARAMETERS][self.keyword]
+        cells = np.asarray(info.get("modified_cells", []), dtype=int)
+        faces = np.asarray(info.get("modified_faces", []), dtype=int)
+        ent = self._contexts.get(id(sd))
+        remapped = "map_cells" in info or "map_faces" in info
+        if remapped or ent is None or ent[0] is not sd or not ent[1].has_mpsa_discretization:
+            saved = {k: pd.pop(k, None) for k in ("specified_cells", "specified_faces", "specified_nodes")}
+            if ent is not None and remapped:
+                self._contexts.pop(id(sd), None)  # the grid itself changed: upload it again
+            try:
+                self.discretize(sd, data)
+            finally:
+                pd.update({k: v for k, v in saved.items() if v is not None})
+            return
+        if cells.size == 0 and faces.size == 0:
+            return
+        if cells.size:
+            pd["specified_cells"] = cells
+        if faces.size:
+            pd["specified_faces"] = faces
+        was = pd.get("update_discretization", False)
+        pd["update_discretization"] = True
+        try:
+            self.discretize(sd, data)
+        finally:
+            pd["update_discretization"] = was
 
     def _assemble(self, sd, data):
         pd = data[PARAMETERS][self.keyword]

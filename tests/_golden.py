@@ -20,7 +20,7 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "partial_", "tilted_", "tpfa_"))]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "partial_", "tilted_", "tpfa_"))]
 
 
 def mpsa_case_names():
@@ -172,3 +172,34 @@ class TiltedCase:
         self.ref_rhs = z["ref_rhs"]
         self.vdim = int(z["vdim"]) if "vdim" in z.files else 3
         self.via_mpfa = bool(int(z["via_mpfa"])) if "via_mpfa" in z.files else False
+
+
+class MpsaPartialCase:
+    """Partial MPSA discretization / update fixture (oracle/gen_golden_mpsa_partial.py)."""
+
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.grid["name"] = str(self.grid["name"])
+        self.is_dir, self.is_neu = z["bc_is_dir"], z["bc_is_neu"]
+        self.mu, self.lam, self.mu_new, self.lam_new = z["mu"], z["lam"], z["mu_new"], z["lam_new"]
+        self.modified_cells = z["modified_cells"]
+
+        def mats(prefix, keys):
+            out = {}
+            for k in keys:
+                shape = tuple(int(v) for v in z[f"{prefix}_{k}_shape"])
+                out[k] = sps.csr_matrix((z[f"{prefix}_{k}_data"], z[f"{prefix}_{k}_indices"],
+                                         z[f"{prefix}_{k}_indptr"]), shape=shape)
+            return out
+
+        self.partial = []
+        for i in range(int(z["num_partial"])):
+            spec = {}
+            for kind in ("cells", "faces", "nodes"):
+                v = z[f"p{i}_spec_{kind}"]
+                if not (v.size == 1 and v[0] == -1):
+                    spec["specified_" + kind] = v
+            self.partial.append({"spec": spec, "active_faces": z[f"p{i}_active_faces"], "mats": mats(f"p{i}", MPSA_KEYS)})
+        self.updated = mats("upd", ("stress", "bound_stress"))

@@ -11,7 +11,7 @@ import scipy.sparse.linalg as spla
 
 import porepy_amd as pa
 from oracle import mpfa_oracle as mo
-from tests._golden import ALL_KEYS, Case, PartialCase, TiltedCase, check_pattern, rel_max_err
+from tests._golden import MPSA_KEYS, MpsaPartialCase, ALL_KEYS, Case, PartialCase, TiltedCase, check_pattern, rel_max_err
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMUL_SO = os.path.join(ROOT, "oracle", "_build", "libporefv_emul.so")
@@ -466,3 +466,39 @@ def mpsa_operator_roundtrip(lib, g, seed=0, mode="clamped_bottom"):
     assert info["converged"]
     assert np.linalg.norm(bo - Ao @ x) <= 1e-10 * np.linalg.norm(bo)
     return d, data
+
+
+def check_mpsa_partial_case(lib, name: str):
+    """specified_* and update_discretization for MPSA against the reference (mpsa.py:196-216, 383-487)."""
+    c = MpsaPartialCase(name)
+    g = pa.grid_from_raw(c.grid)
+    nd = g.dim
+    bc = pa.BoundaryConditionVectorial(g)
+    bc.is_dir, bc.is_neu = c.is_dir.copy(), c.is_neu.copy()
+    C = pa.FourthOrderTensor(c.mu, c.lam)
+    full = pa.initialize_data({}, "mech", {"fourth_order_tensor": C, "bc": bc})
+    d_full = pa.Mpsa("mech", library=lib)
+    d_full.discretize(g, full)
+    full_m = {k: v.copy() for k, v in full[pa.DISCRETIZATION_MATRICES]["mech"].items()}
+    for sub in c.partial:
+        data = pa.initialize_data({}, "mech", {"fourth_order_tensor": C, "bc": bc, **sub["spec"]})
+        pa.Mpsa("mech", library=lib).discretize(g, data)
+        af = sub["active_faces"]
+        assert np.array_equal(data[pa.PARAMETERS]["mech"]["active_faces"], af)
+        rows = (nd * af[:, None] + np.arange(nd)[None, :]).ravel()
+        other = np.setdiff1d(np.arange(nd * g.num_faces), rows)
+        for k in MPSA_KEYS:
+            M = data[pa.DISCRETIZATION_MATRICES]["mech"][k]
+            assert rel_max_err(M, sub["mats"][k]) < TOL, (name, sub["spec"], k)
+            assert M[other].nnz == 0
+            assert rel_max_err(M[rows], full_m[k][rows]) < TOL
+    full[pa.PARAMETERS]["mech"]["fourth_order_tensor"] = pa.FourthOrderTensor(c.mu_new, c.lam_new)
+    full["update_discretization"] = {"modified_cells": c.modified_cells}
+    d_full.update_discretization(g, full)
+    for k in ("stress", "bound_stress"):
+        assert rel_max_err(full[pa.DISCRETIZATION_MATRICES]["mech"][k], c.updated[k]) < TOL, (name, "update", k)
+    _, touched = pa.active_indices(g, cells=c.modified_cells)
+    untouched = np.setdiff1d(np.arange(g.num_faces), touched)
+    if untouched.size:
+        rows = (nd * untouched[:, None] + np.arange(nd)[None, :]).ravel()
+        assert np.array_equal(full[pa.DISCRETIZATION_MATRICES]["mech"]["stress"][rows].data, full_m["stress"][rows].data)

@@ -64,3 +64,8 @@ def test_mpsa_rejects_what_it_does_not_cover(lib):
     data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bcv})
     with pytest.raises(NotImplementedError):
         pa.Mpsa("mechanics", library=lib).discretize(g, data)
+
+
+@pytest.mark.parametrize("name", ["mpsapartial_tri2d_4x4", "mpsapartial_tet3d_2x2x2"])
+def test_partial_discretization_and_update(lib, name):
+    P.check_mpsa_partial_case(lib, name)

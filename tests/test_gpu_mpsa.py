@@ -57,3 +57,8 @@ def test_mpsa_deterministic_bitwise(lib):
         a = data1[pa.DISCRETIZATION_MATRICES]["mechanics"][k]
         b = data2[pa.DISCRETIZATION_MATRICES]["mechanics"][k]
         assert np.array_equal(a.data, b.data), k
+
+
+@pytest.mark.parametrize("name", ["mpsapartial_tri2d_4x4", "mpsapartial_tet3d_2x2x2"])
+def test_partial_discretization_and_update(lib, name):
+    P.check_mpsa_partial_case(lib, name)
