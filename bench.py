@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-side", type=int, default=69, help="lattice cells per side (6 tets each)")
     ap.add_argument("--rtol", type=float, default=1e-10)
+    ap.add_argument("--precond", choices=("amg", "jacobi"), default="amg",
+                    help="preconditioner of the BiCGStab solve: aggregation-AMG V-cycle (default) or Jacobi")
     ap.add_argument("--cpu-n-side", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
@@ -221,7 +223,7 @@ def main():
         def step():
             ctx.discretize(rebuild_topology=True)
             ctx.assemble(bv, None, src)
-            return ctx.solve("bicgstab", rtol=args.rtol, maxit=20000, raise_on_fail=False)
+            return ctx.solve("bicgstab", rtol=args.rtol, maxit=20000, raise_on_fail=False, precond=args.precond)
     else:
         sh = D.ShardedMpfa(lp, device=f"cuda:{local_rank}", local_device_index=local_rank, dist=dist)
         ctx = sh.ctx
@@ -229,7 +231,7 @@ def main():
         def step():
             sh.discretize(Kvals, flags, None, eta, skip_vector_source=False, rebuild_topology=True)
             sh.assemble(bv, src)
-            return sh.solve("bicgstab", rtol=args.rtol, maxit=20000)
+            return sh.solve("bicgstab", rtol=args.rtol, maxit=20000, precond=args.precond)
 
     for _ in range(args.warmup):
         x, info = step()
@@ -266,7 +268,8 @@ def main():
             traffic = pmc["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_spmv (CSR SpMV with A, 2 launches per BiCGStab iteration)",
+    spmv_per_it = 2 if args.precond == "jacobi" else 6  # AMG: + 2 V(1,1) cycles x 2 fine-level SpMVs
+    roofline = {"bound": "hbm", "kernel": f"k_spmv (CSR SpMV with A, {spmv_per_it} launches per BiCGStab iteration)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms}
     # assembly kernels (HBM-bound on their CSR output): algorithmic bytes = inputs once + outputs once
@@ -302,8 +305,11 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"3D simplex box, {nc} owned tetrahedra per GPU (n_side={args.n_side}), perturbed "
                                    "nodes, full-tensor anisotropic heterogeneous K, Dirichlet x-faces; "
-                                   "MPFA-O discretize (6 matrices) + div@flux + Jacobi-BiCGStab",
-                       "cells_per_gpu": nc, "krylov": "bicgstab+jacobi", "rtol": args.rtol,
+                                   "MPFA-O discretize (6 matrices) + div@flux + preconditioned BiCGStab",
+                       "cells_per_gpu": nc, "krylov": "bicgstab+" + args.precond, "rtol": args.rtol,
+                       "amg": ({"levels": st["amg_levels"], "operator_complexity": st["amg_operator_complexity"],
+                                "setup_ms": st["amg_setup_ms"], "coarsest_rows": st["amg_coarsest_rows"]}
+                               if args.precond == "amg" else None),
                        "iterations": info["iterations"], "converged": info["converged"],
                        "true_rel_residual": res_true,
                        "global_cells": ncells_total,

@@ -65,6 +65,11 @@ enum { PFV_BC_DIR = 1, PFV_BC_NEU = 2, PFV_BC_ROB = 4, PFV_BC_INTERNAL = 8 };
  * models/solution_strategy.py:830-884; results are judged against its solution) */
 enum { PFV_SOLVE_CG = 0, PFV_SOLVE_BICGSTAB = 1, PFV_SOLVE_GMRES = 2 };
 
+/* preconditioners of pfv_solve: Jacobi (default), or one V(1,1) cycle of a plain-aggregation
+ * algebraic multigrid built on the device from the assembled matrix (pairwise matching on the
+ * strength graph, piecewise-constant prolongation, Galerkin coarse matrices) */
+enum { PFV_PRECOND_JACOBI = 0, PFV_PRECOND_AMG = 1 };
+
 /* flags for pfv_mpfa_discretize */
 enum {
   PFV_DISCR_REBUILD_TOPOLOGY = 1, /* redo sub-cell topology + CSR symbolic phase even if
@@ -91,6 +96,9 @@ typedef struct {
   double solve_ms;
   double bytes_written_outputs; /* 8*nnz (+4*nnz per distinct pattern) of what was filled */
   int64_t num_nodes, num_sub_half_faces, sum_block_sq, max_block;
+  double amg_setup_ms;            /* last AMG hierarchy build */
+  double amg_operator_complexity; /* sum of nnz over the levels / nnz of the system */
+  int64_t amg_levels, amg_coarsest_rows;
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);
@@ -166,6 +174,9 @@ pfv_status pfv_spmv(pfv_ctx* h, int which, const double* x, double* y);
 pfv_status pfv_set_system(pfv_ctx* h, int64_t n, const int32_t* indptr, const int32_t* indices,
                           const double* data, const double* rhs);
 
+/* Select the preconditioner of the following pfv_solve calls on this handle. */
+pfv_status pfv_set_preconditioner(pfv_ctx* h, int kind);
+
 /* Jacobi-preconditioned Krylov solve of A x = b on the device (stand-in for
  * SolutionStrategy.solve_linear_system, models/solution_strategy.py:830-884).
  * x0 may be NULL (zero start); x receives Nc values. */
@@ -205,6 +216,13 @@ pfv_status pfv_get_device_rhs(pfv_ctx* h, double** d_b, double** d_diag);
 /* device-to-device copy of an internal vector into caller memory (e.g. a torch tensor):
  * which = 0 right-hand side b (Nc), 1 diagonal of A (Nc) */
 pfv_status pfv_copy_device_vector(pfv_ctx* h, int which, double* d_dst, int64_t count);
+/* Block preconditioner of a sharded solve: aggregation-AMG hierarchy of the leading
+ * n_own x n_own block of the active system (a rank's owned cells; couplings to halo columns are
+ * dropped), then one V-cycle per call on device vectors of length n_own -- no communication
+ * inside the preconditioner.  n_own = 0 means the whole active system. */
+pfv_status pfv_amg_setup(pfv_ctx* h, int64_t n_own);
+pfv_status pfv_amg_apply_device(pfv_ctx* h, const double* d_r, double* d_z);
+
 /* run this handle's work on an externally owned HIP stream (hipStream_t passed as void*, e.g.
  * torch.cuda.current_stream().cuda_stream) so that it is ordered with the caller's kernels and
  * RCCL collectives; NULL restores the handle's own stream */

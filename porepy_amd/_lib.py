@@ -35,7 +35,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device",
 ]
 
 
@@ -49,7 +49,9 @@ class Stats(C.Structure):
                 ("face_ms", C.c_double), ("assemble_ms", C.c_double), ("solve_ms", C.c_double),
                 ("bytes_written_outputs", C.c_double), ("num_nodes", C.c_int64),
                 ("num_sub_half_faces", C.c_int64), ("sum_block_sq", C.c_int64),
-                ("max_block", C.c_int64)]
+                ("max_block", C.c_int64), ("amg_setup_ms", C.c_double),
+                ("amg_operator_complexity", C.c_double), ("amg_levels", C.c_int64),
+                ("amg_coarsest_rows", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -90,6 +92,12 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpfa_discretize_faces.restype = C.c_int
     lib.pfv_mpsa_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int]
     lib.pfv_mpsa_discretize_faces.restype = C.c_int
+    lib.pfv_amg_setup.argtypes = [_h, C.c_int64]
+    lib.pfv_amg_setup.restype = C.c_int
+    lib.pfv_amg_apply_device.argtypes = [_h, C.c_void_p, C.c_void_p]
+    lib.pfv_amg_apply_device.restype = C.c_int
+    lib.pfv_set_preconditioner.argtypes = [_h, C.c_int]
+    lib.pfv_set_preconditioner.restype = C.c_int
     lib.pfv_tpfa_discretize.argtypes = [_h, C.c_int]
     lib.pfv_tpfa_discretize.restype = C.c_int
     lib.pfv_set_system.argtypes = [_h, C.c_int64, _ip, _ip, _dp, _dp]
@@ -350,10 +358,11 @@ class Context:
         return y
 
     def solve(self, method="bicgstab", rtol=1e-12, maxit=10000, x0=None, raise_on_fail=True, n=None,
-              restart=0):
+              restart=0, precond="jacobi"):
         """Solve the system assembled last (flow: n = Nc; mechanics: pass n = nd * Nc).
-        ``restart``: GMRES cycle length (0 = 30)."""
+        ``restart``: GMRES cycle length (0 = 30); ``precond``: "jacobi" or "amg"."""
         code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB, "gmres": SOLVE_GMRES}[method]
+        self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1}[precond]))
         x = np.empty(self.nc if n is None else int(n), dtype=np.float64)
         x0a = None if x0 is None else _f64(x0)
         info = SolveInfo()
@@ -396,6 +405,14 @@ class Context:
 
     def copy_device_vector(self, which: int, dst_ptr: int, count: int):
         self._check(self.lib.pfv_copy_device_vector(self._h, which, C.c_void_p(dst_ptr), int(count)))
+
+    def amg_setup(self, n_own: int = 0):
+        """AMG hierarchy of the leading n_own x n_own block of the assembled system (0 = all of it)."""
+        self._check(self.lib.pfv_amg_setup(self._h, int(n_own)))
+
+    def amg_apply_device(self, r_ptr: int, z_ptr: int):
+        """z = V-cycle(r) on device vectors (length of the block given to amg_setup)."""
+        self._check(self.lib.pfv_amg_apply_device(self._h, C.c_void_p(r_ptr), C.c_void_p(z_ptr)))
 
     def set_stream(self, stream_ptr: int | None):
         self._check(self.lib.pfv_set_stream(self._h, C.c_void_p(stream_ptr or 0)))

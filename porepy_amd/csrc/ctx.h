@@ -3,6 +3,9 @@
 #include "../../include/porefv.h"
 #include "backend.h"
 
+#include <memory>
+#include <vector>
+
 namespace pfv {
 
 constexpr int kMaxFaceNodes = 8;   // nodes per face supported by the merge kernels
@@ -37,7 +40,11 @@ struct LinSys {
   bool valid = false;
 };
 
+struct Amg;  // amg.inc
+
 struct pfv_ctx_impl {
+  pfv_ctx_impl();
+  ~pfv_ctx_impl();  // defined where Amg is complete (porefv.hip)
   int device = 0;
   stream_t stream{};      // stream all work of this handle is issued on
   stream_t own_stream{};  // the stream created with the handle (stream may point elsewhere, pfv_set_stream)
@@ -130,6 +137,13 @@ struct pfv_ctx_impl {
   std::vector<int32_t> mpsa_class_lds;  // LDS bytes of the largest node per block-size class
   Buf<double> rhs_m, diag_m;
   LinSys active;                     // what pfv_solve / pfv_get_rhs operate on
+  int active_bs = 1;                 // unknowns per cell of the active system (AMG block size)
+  int precond = 0;                   // PFV_PRECOND_*
+  std::unique_ptr<Amg> amg;          // hierarchy of the active system (rebuilt when the system changes)
+  const double* amg_for_val = nullptr;  // the matrix values the hierarchy was built from
+  std::unique_ptr<Amg> amg_block;    // pfv_amg_setup: hierarchy of the leading block (sharded solves)
+  CsrPattern pat_block;
+  Buf<double> val_block;
 
   pfv_stats stats{};
 

@@ -12,6 +12,11 @@
 #include "mpsa.inc"
 #include "tpfa.inc"
 
+namespace pfv {
+pfv_ctx_impl::pfv_ctx_impl() = default;
+pfv_ctx_impl::~pfv_ctx_impl() = default;
+}  // namespace pfv
+
 using pfv::be_d2h;
 using pfv::be_h2d;
 using pfv::Error;
@@ -331,7 +336,10 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     if (d_vs) be_h2d(d_vs, vector_source, nvs * sizeof(double), s);
     if (d_src) be_h2d(d_src, source, nc * sizeof(double), s);
     tm.start(s);
-    if (!h->have_system) pfv::assemble_system(*h);
+    if (!h->have_system) {
+      pfv::assemble_system(*h);
+      if (h->amg) h->amg->valid = false;
+    }
     pfv::assemble_rhs(*h, d_bc, d_vs, d_src);
     h->stats.assemble_ms = tm.stop(s);
     h->have_system = true;
@@ -340,6 +348,7 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     h->active.diag = h->diag.p;
     h->active.rhs = h->rhs.p;
     h->active.n = h->nc;
+    h->active_bs = 1;
     h->active.valid = true;
   });
 }
@@ -459,7 +468,10 @@ pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     }
     pfv::Timer tm;
     tm.start(s);
-    if (!h->have_mech_system) pfv::mpsa_assemble_system(*h);
+    if (!h->have_mech_system) {
+      pfv::mpsa_assemble_system(*h);
+      if (h->amg) h->amg->valid = false;
+    }
     pfv::mpsa_assemble_rhs(*h, in, d_src);
     h->stats.assemble_ms = tm.stop(s);
     h->have_mech_system = true;
@@ -468,6 +480,7 @@ pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     h->active.diag = h->diag_m.p;
     h->active.rhs = h->rhs_m.p;
     h->active.n = h->nc * h->nd;
+    h->active_bs = h->nd;
     h->active.valid = true;
   });
 }
@@ -606,7 +619,81 @@ pfv_status pfv_set_system(pfv_ctx* h, int64_t n, const int32_t* indptr, const in
     h->active.diag = dg;
     h->active.rhs = b;
     h->active.n = n;
+    h->active_bs = 1;
+    if (h->amg) h->amg->valid = false;
     h->active.valid = true;
+  });
+}
+
+pfv_status pfv_amg_setup(pfv_ctx* h, int64_t n_own) {
+  return guarded(h, [&] {
+    require(h->active.valid, "assemble first");
+    const int bs = h->active_bs;
+    const int64_t n = h->active.n;
+    if (n_own <= 0) n_own = n;
+    require(n_own <= n && n_own % bs == 0, "bad block size");
+    auto s = h->stream;
+    if (!h->amg_block) h->amg_block = std::make_unique<pfv::Amg>();
+    h->amg_block->valid = false;
+    const pfv::CsrPattern* P = h->active.P;
+    const double* val = h->active.val;
+    if (n_own < n) {
+      // leading block: drop the columns >= n_own (halo cells of the subdomain)
+      const int32_t* ip = P->indptr;
+      const int32_t* ix = P->indices;
+      pfv::Buf<int32_t> len;
+      pfv::Buf<int64_t> pos;
+      int32_t* ln = len.ensure(n_own + 1);
+      int64_t* ps = pos.ensure(n_own + 1);
+      pfv::parallel_for(s, n_own, PFV_LAMBDA(int64_t r) {
+        int m = 0;
+        for (int e = ip[r]; e < ip[r + 1]; ++e) m += ix[e] < n_own ? 1 : 0;
+        ln[r] = m;
+      });
+      pfv::exclusive_scan<int32_t, int64_t>(s, h->scratch, ln, ps, (size_t)n_own);
+      const int64_t nnz = pfv::read_scalar<int64_t>(s, ps + n_own);
+      pfv::CsrPattern& B = h->pat_block;
+      B.nrows = B.ncols = n_own;
+      B.nnz = nnz;
+      B.max_row = P->max_row;
+      int32_t* bp = B.indptr.ensure(n_own + 1);
+      int32_t* bx = B.indices.ensure(std::max<int64_t>(nnz, 1));
+      double* bv = h->val_block.ensure(std::max<int64_t>(nnz, 1));
+      pfv::parallel_for(s, n_own + 1, PFV_LAMBDA(int64_t r) {
+        bp[r] = (int32_t)ps[r];
+        if (r < n_own) {
+          int64_t o = ps[r];
+          for (int e = ip[r]; e < ip[r + 1]; ++e)
+            if (ix[e] < n_own) {
+              bx[o] = ix[e];
+              bv[o] = val[e];
+              ++o;
+            }
+        }
+      });
+      P = &B;
+      val = bv;
+    }
+    pfv::amg_setup(*h, *h->amg_block, *P, val, bs);
+    h->stats.amg_setup_ms = h->amg_block->setup_ms;
+    h->stats.amg_operator_complexity = h->amg_block->op_complexity;
+    h->stats.amg_levels = (int64_t)h->amg_block->lev.size();
+    h->stats.amg_coarsest_rows = h->amg_block->lev.back()->n;
+  });
+}
+
+pfv_status pfv_amg_apply_device(pfv_ctx* h, const double* d_r, double* d_z) {
+  return guarded(h, [&] {
+    require(h->amg_block && h->amg_block->valid, "pfv_amg_setup first");
+    require(d_r && d_z && d_r != d_z, "bad vectors");
+    pfv::amg_cycle(*h, *h->amg_block, 0, d_r, d_z);
+  });
+}
+
+pfv_status pfv_set_preconditioner(pfv_ctx* h, int kind) {
+  return guarded(h, [&] {
+    require(kind == PFV_PRECOND_JACOBI || kind == PFV_PRECOND_AMG, "unknown preconditioner");
+    h->precond = kind;
   });
 }
 
@@ -625,8 +712,24 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
     if (x0) be_h2d(dx, x0, n * sizeof(double), s); else pfv::be_memset(dx, 0, n * sizeof(double), s);
     pfv::Timer tm;
     tm.start(s);
-    res = method == PFV_SOLVE_GMRES ? pfv::gmres_solve(*h, h->active, rtol, maxit, restart, dx, x0 == nullptr)
-                                    : pfv::krylov_solve(*h, h->active, method, rtol, maxit, dx, x0 == nullptr);
+    pfv::Precond M;
+    const pfv::Precond* Mp = nullptr;
+    if (h->precond == PFV_PRECOND_AMG) {
+      if (!h->amg) h->amg = std::make_unique<pfv::Amg>();
+      if (!h->amg->valid || h->amg_for_val != h->active.val) {
+        pfv::amg_setup(*h, *h->amg, *h->active.P, h->active.val, h->active_bs);
+        h->amg_for_val = h->active.val;
+        h->stats.amg_setup_ms = h->amg->setup_ms;
+        h->stats.amg_operator_complexity = h->amg->op_complexity;
+        h->stats.amg_levels = (int64_t)h->amg->lev.size();
+        h->stats.amg_coarsest_rows = h->amg->lev.back()->n;
+      }
+      M.amg = h->amg.get();
+      Mp = &M;
+    }
+    res = method == PFV_SOLVE_GMRES
+              ? pfv::gmres_solve(*h, h->active, rtol, maxit, restart, dx, x0 == nullptr, Mp)
+              : pfv::krylov_solve(*h, h->active, method, rtol, maxit, dx, x0 == nullptr, Mp);
     h->stats.solve_ms = tm.stop(s);
     be_d2h(x, dx, n * sizeof(double), s);
   });

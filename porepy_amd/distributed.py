@@ -196,6 +196,7 @@ class ShardedMpfa:
         self.n_loc = lp.raw["cell_centers"].shape[1]
         self.plan = HaloPlan(lp, dist).to(self.device)
         self._b = self._diag = None
+        self._amg_ready = False
 
     # boundary flags of the local grid: true boundary faces keep theirs; faces that are one-sided
     # only because the neighbour is outside the local grid are Neumann (they never touch a node of
@@ -213,6 +214,7 @@ class ShardedMpfa:
     def assemble(self, bc_values_local, source_local=None):
         torch = self.torch
         self.ctx.assemble(bc_values_local, None, source_local)
+        self._amg_ready = False  # the matrix may have changed
         self._b = torch.empty(self.n_loc, dtype=torch.float64, device=self.device)
         self._diag = torch.empty(self.n_loc, dtype=torch.float64, device=self.device)
         self._use_torch_stream()
@@ -232,14 +234,33 @@ class ShardedMpfa:
         self.plan.exchange(x_full)
         self.ctx.spmv_device_rows(_lib.MAT_SYSTEM, self.n_own, x_full.data_ptr(), out_owned.data_ptr())
 
-    def solve(self, method: str = "bicgstab", rtol: float = 1e-10, maxit: int = 20000, check_every: int = 10):
-        """Returns (x_owned as a torch tensor, info)."""
+    def solve(self, method: str = "bicgstab", rtol: float = 1e-10, maxit: int = 20000, check_every: int = 10,
+              precond: str = "jacobi"):
+        """Returns (x_owned as a torch tensor, info).  precond = "amg": every rank applies one V-cycle of
+        the aggregation AMG of its own diagonal block (owned cells x owned cells) -- block Jacobi
+        across ranks, no communication inside the preconditioner."""
         torch = self.torch
         n, dev = self.n_own, self.device
         self._use_torch_stream()
         b = self._b[:n]
         dinv = 1.0 / self._diag[:n]
         f64 = dict(dtype=torch.float64, device=dev)
+        if precond == "amg":
+            if not self._amg_ready:
+                self.ctx.amg_setup(n)
+                self._amg_ready = True
+            check_every = 1
+
+            def apply_M(vec):
+                out = torch.empty(n, **f64)
+                vec = vec.contiguous()
+                self.ctx.amg_apply_device(vec.data_ptr(), out.data_ptr())
+                return out
+        elif precond == "jacobi":
+            def apply_M(vec):
+                return vec * dinv
+        else:
+            raise ValueError("precond must be 'jacobi' or 'amg'")
         x = torch.zeros(n, **f64)
         r = b.clone()
         full = torch.zeros(self.n_loc, **f64)   # owned + halo staging vector for the SpMV input
@@ -252,7 +273,7 @@ class ShardedMpfa:
             return x, info
         tol2 = rtol * rtol * bbh
         if method == "cg":
-            z = r * dinv
+            z = apply_M(r)
             p = z.clone()
             v = torch.empty(n, **f64)
             red = self._allreduce(torch.stack((torch.dot(r, r), torch.dot(r, z))))
@@ -263,7 +284,7 @@ class ShardedMpfa:
                 alpha = rho / self._allreduce(torch.dot(p, v).reshape(1))[0]
                 x += alpha * p
                 r -= alpha * v
-                z = r * dinv
+                z = apply_M(r)
                 red = self._allreduce(torch.stack((torch.dot(r, r), torch.dot(r, z))))
                 beta = red[1] / rho
                 rho = red[1]
@@ -289,12 +310,12 @@ class ShardedMpfa:
         for it in range(1, maxit + 1):
             beta = (rho / rho_old) * (alpha / omega)
             p = r + beta * (p - omega * v)
-            y = p * dinv
+            y = apply_M(p)
             full[:n] = y
             self._spmv_owned(full, v)
             alpha = rho / self._allreduce(torch.dot(rhat, v).reshape(1))[0]
             s = r - alpha * v
-            z = s * dinv
+            z = apply_M(s)
             full[:n] = z
             self._spmv_owned(full, t)
             red2 = self._allreduce(torch.stack((torch.dot(t, s), torch.dot(t, t))))

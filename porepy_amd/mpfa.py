@@ -260,20 +260,20 @@ class Mpfa:
 
     # ---- solve (stand-in for SolutionStrategy.solve_linear_system) --------------------
     def solve(self, sd, data: dict, source=None, method: str = "bicgstab", rtol: float = 1e-12,
-              maxit: int = 20000, x0=None, restart: int = 0):
-        """Solve A p = b + source with the Jacobi-preconditioned Krylov solver on the device
-        (method: "bicgstab", "gmres" (restart = cycle length) or "cg"), re-using the
-        device-resident system.  Returns (p, info)."""
+              maxit: int = 20000, x0=None, restart: int = 0, precond: str = "jacobi"):
+        """Solve A p = b + source with a Krylov solver on the device (method: "bicgstab", "gmres"
+        (restart = cycle length) or "cg"; precond: "jacobi" or "amg" = aggregation multigrid V-cycle),
+        re-using the device-resident system.  Returns (p, info)."""
         if sd.dim < 2:
             return self._tpfa().solve(sd, data, source=source, method=method, rtol=rtol, maxit=maxit, x0=x0,
-                                      restart=restart)
+                                      restart=restart, precond=precond)
         pd = data[PARAMETERS][self.keyword]
         ent = self._contexts.get(id(sd))
         if ent is None or ent[0] is not sd:
             raise RuntimeError("discretize(sd, data) must run on this object before solve")
         ctx = ent[1]
         ctx.assemble(np.asarray(pd["bc_values"], dtype=float), self._vector_source(sd, pd), source)
-        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, restart=restart)
+        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, restart=restart, precond=precond)
 
 
 def as_porepy_discretization(device: int = 0, library=None):

@@ -151,6 +151,7 @@ class Mpsa:
         return ctx.matrix(_lib.MAT_MECH_SYSTEM), ctx.active_rhs(n)
 
     def solve(self, sd, data: dict, method: str = "bicgstab", rtol: float = 1e-12, maxit: int = 50000, x0=None,
-              restart: int = 0):
+              restart: int = 0, precond: str = "jacobi"):
         ctx = self._assemble(sd, data)
-        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, n=sd.dim * sd.num_cells, restart=restart)
+        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, n=sd.dim * sd.num_cells, restart=restart,
+                         precond=precond)

@@ -6,6 +6,7 @@ them to the Jacobi-preconditioned Krylov solvers behind ``pfv_set_system`` / ``p
 
     class Model(porepy_amd.HipLinearSolver, SinglePhaseFlow): ...
     params = {"linear_solver": "hip_bicgstab", ...}      # or "hip_gmres", "hip_cg"
+    params["hip_solver_options"] = {"precond": "amg", "rtol": 1e-12}   # optional
 
 Any other ``linear_solver`` value falls through to the reference implementation.  Systems with
 zero diagonal entries (saddle-point blocks of mixed-dimensional models) are refused by the
@@ -21,11 +22,11 @@ _METHODS = {"hip_bicgstab": "bicgstab", "hip_gmres": "gmres", "hip_cg": "cg"}
 
 
 def solve_csr(A, b, method: str = "bicgstab", rtol: float = 1e-12, maxit: int = 50000, restart: int = 0,
-              device: int = 0, library=None, context: _lib.Context | None = None):
+              device: int = 0, library=None, context: _lib.Context | None = None, precond: str = "jacobi"):
     """x with ||b - A x|| <= rtol ||b||, computed on the device; returns (x, info)."""
     ctx = context if context is not None else _lib.Context(device, library)
     ctx.set_system(A, b)
-    return ctx.solve(method=method, rtol=rtol, maxit=maxit, restart=restart, n=A.shape[0])
+    return ctx.solve(method=method, rtol=rtol, maxit=maxit, restart=restart, n=A.shape[0], precond=precond)
 
 
 class HipLinearSolver:
@@ -52,7 +53,7 @@ class HipLinearSolver:
             self._hip_solver_context = _lib.Context(int(opts.get("device", 0)), self.hip_library)
         x, info = solve_csr(A, b, method=_METHODS[solver], rtol=float(opts.get("rtol", 1e-12)),
                             maxit=int(opts.get("maxit", 50000)), restart=int(opts.get("restart", 0)),
-                            context=self._hip_solver_context)
+                            context=self._hip_solver_context, precond=str(opts.get("precond", "jacobi")))
         self.hip_solver_info = info
         x = np.atleast_1d(x)
         if self._apply_schur_complement_reduction():

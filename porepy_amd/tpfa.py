@@ -99,8 +99,8 @@ class Tpfa:
         return ctx.matrix(_lib.MAT_SYSTEM), ctx.rhs()
 
     def solve(self, sd, data: dict, source=None, method: str = "cg", rtol: float = 1e-12, maxit: int = 20000,
-              x0=None, restart: int = 0):
+              x0=None, restart: int = 0, precond: str = "jacobi"):
         pd = data[PARAMETERS][self.keyword]
         ctx = self._ctx(sd)
         ctx.assemble(np.asarray(pd["bc_values"], dtype=float), pd.get("vector_source", None), source)
-        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, restart=restart)
+        return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, restart=restart, precond=precond)

@@ -393,7 +393,7 @@ def check_mpsa_known_answer(lib, key: str):
     assert np.allclose(stress, c.known_stress)
 
 
-def mpsa_uniaxial_exact(lib, g, tol=1e-10):
+def mpsa_uniaxial_exact(lib, g, tol=1e-10, precond="jacobi"):
     """BASELINE config C4 recipe: mu = lambda = 1, rollers on the low x/y/z faces, unit traction on
     top; exact u = (nu x / E, nu y / E, -z / E), E = 2.5, nu = 0.25."""
     nd = g.dim
@@ -412,7 +412,7 @@ def mpsa_uniaxial_exact(lib, g, tol=1e-10):
     data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "bc_values": bv.ravel("F")})
     d = pa.Mpsa("mechanics", library=lib)
     d.discretize(g, data)
-    u, info = d.solve(g, data, rtol=1e-13)
+    u, info = d.solve(g, data, rtol=1e-13, precond=precond)
     assert info["converged"]
     u = u.reshape(nd, -1, order="F")
     cc = g.cell_centers
@@ -502,3 +502,41 @@ def check_mpsa_partial_case(lib, name: str):
     if untouched.size:
         rows = (nd * untouched[:, None] + np.arange(nd)[None, :]).ravel()
         assert np.array_equal(full[pa.DISCRETIZATION_MATRICES]["mech"]["stress"][rows].data, full_m["stress"][rows].data)
+
+
+def amg_preconditioner(lib, g, seed=2, hetero_sigma=0.5):
+    """Aggregation-AMG-preconditioned solves against the direct solution of the same system, far fewer
+    iterations than Jacobi, bitwise repeatable."""
+    rng = np.random.default_rng(seed)
+    nc = g.num_cells
+    sc = np.exp(hetero_sigma * rng.standard_normal(nc))
+    kw = dict(kxx=sc, kyy=5 * sc, kxy=0.4 * sc)
+    if g.dim == 3:
+        kw.update(kzz=0.2 * sc, kyz=0.1 * sc)
+    K = pa.SecondOrderTensor(**kw)
+    bf = g.get_all_boundary_faces()
+    xf = g.face_centers[0, bf]
+    dirf = bf[(xf < 1e-9) | (xf > g.nodes[0].max() - 1e-9)]
+    bc = pa.BoundaryCondition(g, dirf, ["dir"] * dirf.size)
+    bv = np.zeros(g.num_faces)
+    bv[dirf] = g.face_centers[0, dirf]
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": bv})
+    d = pa.Mpfa("flow", library=lib)
+    d.discretize(g, data)
+    A, b = d.assemble_matrix_rhs(g, data)
+    src = g.cell_volumes
+    xo = spla.spsolve(A.tocsc(), b + src)
+    xj, ij = d.solve(g, data, source=src, rtol=1e-12)
+    out = {}
+    for method in ("bicgstab", "gmres"):
+        x, info = d.solve(g, data, source=src, method=method, rtol=1e-12, precond="amg")
+        assert info["converged"], method
+        assert np.linalg.norm(x - xo) <= TOL * np.linalg.norm(xo), method
+        out[method] = info["iterations"]
+    assert out["bicgstab"] * 4 < ij["iterations"], (out, ij["iterations"])
+    x2, info2 = d.solve(g, data, source=src, method="bicgstab", rtol=1e-12, precond="amg")
+    x3, info3 = d.solve(g, data, source=src, method="bicgstab", rtol=1e-12, precond="amg")
+    assert np.array_equal(x2, x3) and info2["iterations"] == info3["iterations"]
+    st = d.context(g).stats()
+    assert st["amg_levels"] >= 2 and 1.0 < st["amg_operator_complexity"] < 2.0
+    return out, ij["iterations"], st

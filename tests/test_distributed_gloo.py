@@ -47,7 +47,7 @@ def _problem(kind):
     return g, K, bc, bv, src
 
 
-def _worker(rank, world, port, kind, method, out):
+def _worker(rank, world, port, kind, method, out, precond="jacobi"):
     import torch
     import torch.distributed as dist
 
@@ -65,20 +65,23 @@ def _worker(rank, world, port, kind, method, out):
         sh.discretize(K.values[:, :, lp.cell_gid], flags, bc.robin_weight[lp.face_gid], pa.determine_eta(g))
         sh.assemble(bv[lp.face_gid], src[lp.cell_gid])
         A_own, b_own = sh.owned_system_rows()
-        x, info = sh.solve(method=method, rtol=1e-12, maxit=3000, check_every=1)
+        x, info = sh.solve(method=method, rtol=1e-12, maxit=3000, check_every=1, precond=precond)
         torch.save({"gid": lp.cell_gid, "n_own": lp.n_own, "A": A_own, "b": b_own, "x": x.numpy(),
                     "info": info}, os.path.join(out, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,method", [("tet", "bicgstab"), ("cart", "cg")])
-def test_two_rank_sharded_assembly_and_solve(tmp_path, kind, method):
+@pytest.mark.parametrize("kind,method,precond", [("tet", "bicgstab", "jacobi"), ("cart", "cg", "jacobi"),
+                                                 ("tet", "bicgstab", "amg")])
+def test_two_rank_sharded_assembly_and_solve(tmp_path, kind, method, precond):
+    """precond = "amg": each rank preconditions with a V-cycle of its own diagonal block."""
     import torch
     import torch.multiprocessing as mp
 
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), kind, method, str(tmp_path)), nprocs=world, join=True)
+    P.emulation_library()  # build once here, not concurrently in the workers
+    mp.spawn(_worker, args=(world, _free_port(), kind, method, str(tmp_path), precond), nprocs=world, join=True)
     # single-domain reference through the same library
     lib = P.emulation_library()
     g, K, bc, bv, src = _problem(kind)
@@ -147,6 +150,7 @@ def test_bench_slab_decomposition_matches_single_domain(tmp_path):
     import bench
 
     world = 3
+    P.emulation_library()  # build once here, not concurrently in the workers
     mp.spawn(_slab_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     lib = P.emulation_library()
     lp, Kv, flags, bv, src, eta = bench.make_slab_problem(4, 0, 1, layers=3 * world)

@@ -69,3 +69,11 @@ def test_mpsa_rejects_what_it_does_not_cover(lib):
 @pytest.mark.parametrize("name", ["mpsapartial_tri2d_4x4", "mpsapartial_tet3d_2x2x2"])
 def test_partial_discretization_and_update(lib, name):
     P.check_mpsa_partial_case(lib, name)
+
+
+def test_amg_block_preconditioner_for_mechanics(lib):
+    """bs = nd unknowns per cell: cells are aggregated, components kept apart."""
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([5, 5, 5], [1, 1, 1])), 0.03)
+    info = P.mpsa_uniaxial_exact(lib, g, tol=1e-9, precond="amg")
+    base = P.mpsa_uniaxial_exact(lib, g, tol=1e-9)
+    assert info["iterations"] * 2 < base["iterations"], (info, base)

@@ -195,3 +195,28 @@ def test_tpfa_and_1d_delegation(lib, name):
 
 def test_zero_dimensional_grid(lib):
     P.check_zero_dimensional_grid(lib)
+
+
+def test_amg_preconditioner(lib):
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([10, 10, 10], [1, 1, 1])), 0.02)
+    out, jac, st = P.amg_preconditioner(lib, g)
+    # strongly heterogeneous Cartesian grid: matching runs out of strong neighbours early
+    g = _geo(pa.CartGrid([14, 14, 14], [1, 1, 1]))
+    P.amg_preconditioner(lib, g, hetero_sigma=2.0)
+    g = _geo(pa.CartGrid([40, 30], [1, 1]))
+    P.amg_preconditioner(lib, g)
+
+
+def test_amg_on_assembled_csr_and_symmetric_cg(lib):
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+
+    n = 60
+    T = sps.diags([-1, 2, -1], [-1, 0, 1], shape=(n, n))
+    A = (sps.kron(sps.identity(n), T) + sps.kron(T, sps.identity(n))).tocsr()
+    b = np.ones(n * n)
+    xo = spla.spsolve(A.tocsc(), b)
+    xj, ij = pa.solve_csr(A, b, method="cg", rtol=1e-12, library=lib)
+    xa, ia = pa.solve_csr(A, b, method="cg", rtol=1e-12, library=lib, precond="amg")
+    assert np.linalg.norm(xa - xo) <= 1e-10 * np.linalg.norm(xo)
+    assert ia["iterations"] * 2 < ij["iterations"]

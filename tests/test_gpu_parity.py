@@ -179,3 +179,12 @@ def test_tpfa_and_1d_delegation(lib, name):
 
 def test_zero_dimensional_grid(lib):
     P.check_zero_dimensional_grid(lib)
+
+
+def test_amg_preconditioner(lib):
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([12, 12, 12], [1, 1, 1])), 0.015)
+    P.amg_preconditioner(lib, g)
+    g = _geo(pa.CartGrid([14, 14, 14], [1, 1, 1]))
+    P.amg_preconditioner(lib, g, hetero_sigma=2.0)
+    g = _geo(pa.CartGrid([40, 30], [1, 1]))
+    P.amg_preconditioner(lib, g)
