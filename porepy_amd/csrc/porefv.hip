@@ -674,11 +674,11 @@ pfv_status pfv_amg_setup(pfv_ctx* h, int64_t n_own) {
       P = &B;
       val = bv;
     }
-    pfv::amg_setup(*h, *h->amg_block, *P, val, bs);
+    pfv::amg_setup(*h, *h->amg_block, *P, val, bs, h->active.diag);  // the leading block keeps its diagonal
     h->stats.amg_setup_ms = h->amg_block->setup_ms;
     h->stats.amg_operator_complexity = h->amg_block->op_complexity;
-    h->stats.amg_levels = (int64_t)h->amg_block->lev.size();
-    h->stats.amg_coarsest_rows = h->amg_block->lev.back()->n;
+    h->stats.amg_levels = (int64_t)h->amg_block->nlev;
+    h->stats.amg_coarsest_rows = h->amg_block->lev[h->amg_block->nlev - 1]->n;
   });
 }
 
@@ -717,12 +717,12 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
     if (h->precond == PFV_PRECOND_AMG) {
       if (!h->amg) h->amg = std::make_unique<pfv::Amg>();
       if (!h->amg->valid || h->amg_for_val != h->active.val) {
-        pfv::amg_setup(*h, *h->amg, *h->active.P, h->active.val, h->active_bs);
+        pfv::amg_setup(*h, *h->amg, *h->active.P, h->active.val, h->active_bs, h->active.diag);
         h->amg_for_val = h->active.val;
         h->stats.amg_setup_ms = h->amg->setup_ms;
         h->stats.amg_operator_complexity = h->amg->op_complexity;
-        h->stats.amg_levels = (int64_t)h->amg->lev.size();
-        h->stats.amg_coarsest_rows = h->amg->lev.back()->n;
+        h->stats.amg_levels = (int64_t)h->amg->nlev;
+        h->stats.amg_coarsest_rows = h->amg->lev[h->amg->nlev - 1]->n;
       }
       M.amg = h->amg.get();
       Mp = &M;

@@ -188,3 +188,32 @@ def test_amg_preconditioner(lib):
     P.amg_preconditioner(lib, g, hetero_sigma=2.0)
     g = _geo(pa.CartGrid([40, 30], [1, 1]))
     P.amg_preconditioner(lib, g)
+
+
+def test_sharded_driver_single_rank_with_block_amg(lib):
+    """The multi-GPU driver on one rank (no exchange): device-pointer SpMV, block-AMG V-cycles on torch
+    tensors, against the single-context solve."""
+    import torch
+
+    from porepy_amd import distributed as D
+
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([10, 10, 10], [1, 1, 1])), 0.02)
+    rng = np.random.default_rng(1)
+    k = np.exp(0.5 * rng.standard_normal(g.num_cells))
+    K = pa.SecondOrderTensor(kxx=k, kyy=6 * k, kzz=0.3 * k, kxy=0.3 * k)
+    bf = g.get_all_boundary_faces()
+    dirf = bf[(g.face_centers[0, bf] < 1e-9) | (g.face_centers[0, bf] > 1 - 1e-9)]
+    bc = pa.BoundaryCondition(g, dirf, ["dir"] * dirf.size)
+    bv = np.zeros(g.num_faces)
+    bv[dirf] = g.face_centers[0, dirf]
+    raw = pa.grid_to_raw(g)
+    lp = D.extract_subdomain(raw, np.zeros(g.num_cells, dtype=np.int64), 0)
+    sh = D.ShardedMpfa(lp, device="cuda:0", local_device_index=0, library=lib)
+    sh.discretize(K.values[:, :, lp.cell_gid], sh.local_bc_flags(pa.bc_flags(bc)[lp.face_gid]), None, 1.0 / 3.0)
+    sh.assemble(bv[lp.face_gid], g.cell_volumes[lp.cell_gid])
+    xj, ij = sh.solve("bicgstab", rtol=1e-12, check_every=1)
+    xa, ia = sh.solve("bicgstab", rtol=1e-12, precond="amg")
+    assert ia["converged"] and ia["iterations"] * 4 < ij["iterations"]
+    xa, xj = xa.cpu().numpy(), xj.cpu().numpy()
+    assert np.linalg.norm(xa - xj) <= 1e-9 * np.linalg.norm(xj)
+    torch.cuda.synchronize()
