@@ -225,8 +225,11 @@ pfv_status pfv_amg_apply_device(pfv_ctx* h, const double* d_r, double* d_z);
 
 /* run this handle's work on an externally owned HIP stream (hipStream_t passed as void*, e.g.
  * torch.cuda.current_stream().cuda_stream) so that it is ordered with the caller's kernels and
- * RCCL collectives; NULL restores the handle's own stream */
+ * RCCL collectives.  NULL is the legacy default stream (what torch's default stream is) -- the
+ * handle's own stream is non-blocking and is NOT ordered with it; pfv_reset_stream goes back to
+ * the handle's own stream. */
 pfv_status pfv_set_stream(pfv_ctx* h, void* hip_stream);
+pfv_status pfv_reset_stream(pfv_ctx* h);
 pfv_status pfv_sync(pfv_ctx* h);
 
 pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out);

@@ -35,7 +35,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream",
 ]
 
 
@@ -92,6 +92,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpfa_discretize_faces.restype = C.c_int
     lib.pfv_mpsa_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int]
     lib.pfv_mpsa_discretize_faces.restype = C.c_int
+    lib.pfv_reset_stream.argtypes = [_h]
+    lib.pfv_reset_stream.restype = C.c_int
     lib.pfv_amg_setup.argtypes = [_h, C.c_int64]
     lib.pfv_amg_setup.restype = C.c_int
     lib.pfv_amg_apply_device.argtypes = [_h, C.c_void_p, C.c_void_p]
@@ -415,7 +417,11 @@ class Context:
         self._check(self.lib.pfv_amg_apply_device(self._h, C.c_void_p(r_ptr), C.c_void_p(z_ptr)))
 
     def set_stream(self, stream_ptr: int | None):
+        """Run on the caller's HIP stream (0 / None = the legacy default stream, torch's default)."""
         self._check(self.lib.pfv_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def reset_stream(self):
+        self._check(self.lib.pfv_reset_stream(self._h))
 
     def debug_array(self, which: int) -> np.ndarray:
         """Internal per-node operator rows (0: A^-1, 1: T), for tests."""

@@ -553,7 +553,16 @@ pfv_status pfv_set_stream(pfv_ctx* h, void* hip_stream) {
     (void)hip_stream;
 #else
     pfv::be_sync(h->stream);
-    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = the legacy default stream
+#endif
+  });
+}
+
+pfv_status pfv_reset_stream(pfv_ctx* h) {
+  return guarded(h, [&] {
+#ifndef PFV_EMULATE
+    pfv::be_sync(h->stream);
+    h->stream = h->own_stream;
 #endif
   });
 }
