@@ -182,6 +182,8 @@ def main():
     ap.add_argument("--cpu-n-side", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N > 1 code path (torch-driven sharded solver) on one GPU, for validation")
     args = ap.parse_args()
 
     import torch
@@ -214,7 +216,7 @@ def main():
     lp, Kvals, flags, bv, src, eta = make_slab_problem(args.n_side, rank, world)
     nc = lp.n_own                      # cells this rank owns (halo cells are recomputed, not counted)
     nloc = lp.raw["cell_centers"].shape[1]
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         ctx = pa.Context(local_rank)
         ctx.set_grid(lp.raw)
         ctx.set_params(Kvals, flags, None, eta)
@@ -295,7 +297,8 @@ def main():
             if world == 1:
                 A = ctx.matrix(pa._lib.MAT_SYSTEM)
                 b = ctx.rhs()
-                res_true = float(np.linalg.norm(b - A @ x) / np.linalg.norm(b))
+                xh = x if isinstance(x, np.ndarray) else x.cpu().numpy()
+                res_true = float(np.linalg.norm(b - A @ xh) / np.linalg.norm(b))
         except Exception:
             pass
         line = {
