@@ -21,8 +21,10 @@ for it in range(2):
     st = ctx.stats()
     print(f"cells {nc}: discretize {dt*1e3:.1f} ms  (topology {st['topology_ms']:.1f} symbolic {st['symbolic_ms']:.1f} node {st['node_ms']:.1f} face {st['face_ms']:.1f})  {nc/dt/1e6:.2f} Mcells/s", flush=True)
 t = time.perf_counter(); ctx.mpsa_assemble(bv.ravel("F"), None); ctx.sync(); print("assemble ms", (time.perf_counter()-t)*1e3, ctx.stats()["assemble_ms"])
-u, info = ctx.solve("bicgstab", rtol=1e-10, maxit=50000, n=3*nc, raise_on_fail=False)
-print("solve", info)
+pre = sys.argv[2] if len(sys.argv) > 2 else "amg"
+u, info = ctx.solve("bicgstab", rtol=1e-10, maxit=50000, n=3*nc, raise_on_fail=False, precond=pre)
+st = ctx.stats()
+print("solve", pre, info, {k: st[k] for k in st if k.startswith("amg")})
 u = u.reshape(3, -1, order="F"); cc = g.cell_centers; E, nu = 2.5, 0.25
 print("max error vs exact uniaxial solution", np.max(np.abs(u - np.vstack((nu*cc[0]/E, nu*cc[1]/E, -cc[2]/E)))))
 print("A nnz", ctx.matrix_info(11))
