@@ -191,6 +191,13 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
  * eta as in pfv_mpfa_set_params (scalar). */
 pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const double* cell_volumes,
                                const uint8_t* bc_dir_bits, const uint8_t* bc_neu_bits, double eta);
+/* Robin conditions of the vectorial boundary condition (BoundaryConditionVectorial.is_rob,
+ * .robin_weight, params/bc.py:222-322; rows of numerics/fv/mpsa.py:1381-1459): bit c of
+ * bc_rob_bits[f] = component c of face f is Robin; robin_weight_ddn = weights W[i][a][f], shape
+ * (nd, nd, Nf) C-order (NULL = identity).  Call after pfv_mpsa_set_params (which clears them);
+ * bc_rob_bits = NULL removes them.  Cartesian basis only. */
+pfv_status pfv_mpsa_set_robin(pfv_ctx* h, const uint8_t* bc_rob_bits, const double* robin_weight_ddn);
+
 /* Mpsa._stress_discretization (numerics/fv/mpsa.py:531-782) on the device; fills matrices 7-10 */
 pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags);
 

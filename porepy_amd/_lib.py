@@ -35,7 +35,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin",
 ]
 
 
@@ -92,6 +92,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpfa_discretize_faces.restype = C.c_int
     lib.pfv_mpsa_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int]
     lib.pfv_mpsa_discretize_faces.restype = C.c_int
+    lib.pfv_mpsa_set_robin.argtypes = [_h, _up, _dp]
+    lib.pfv_mpsa_set_robin.restype = C.c_int
     lib.pfv_reset_stream.argtypes = [_h]
     lib.pfv_reset_stream.restype = C.c_int
     lib.pfv_amg_setup.argtypes = [_h, C.c_int64]
@@ -244,7 +246,7 @@ class Context:
                                                  _ptr(rw, _dp), float(eta), _ptr(es, _dp)))
 
     # ---- MPSA ----------------------------------------------------------------------
-    def mpsa_set_params(self, stiffness, cell_volumes, is_dir, is_neu, eta=0.0):
+    def mpsa_set_params(self, stiffness, cell_volumes, is_dir, is_neu, eta=0.0, is_rob=None, robin_weight=None):
         C9 = _f64(stiffness)
         if C9.shape != (9, 9, self.nc):
             raise ValueError(f"stiffness must have shape (9, 9, {self.nc})")
@@ -257,6 +259,17 @@ class Context:
         nbits = np.ascontiguousarray((is_neu * wts).sum(axis=0), dtype=np.uint8)
         self._check(self.lib.pfv_mpsa_set_params(self._h, _ptr(C9, _dp), _ptr(vol, _dp), _ptr(dbits, _up),
                                                  _ptr(nbits, _up), float(eta)))
+        if is_rob is not None and np.any(is_rob):
+            is_rob = np.asarray(is_rob, bool)
+            if is_rob.shape != (self.nd, self.nf):
+                raise AttributeError("is_rob must have shape (nd, Nf)")
+            rbits = np.ascontiguousarray((is_rob * wts).sum(axis=0), dtype=np.uint8)
+            W = None
+            if robin_weight is not None:
+                W = _f64(robin_weight)
+                if W.shape != (self.nd, self.nd, self.nf):
+                    raise ValueError("robin_weight must have shape (nd, nd, Nf)")
+            self._check(self.lib.pfv_mpsa_set_robin(self._h, _ptr(rbits, _up), _ptr(W, _dp)))
 
     def mpsa_discretize(self, rebuild_topology=False):
         self._check(self.lib.pfv_mpsa_discretize(self._h, DISCR_REBUILD_TOPOLOGY if rebuild_topology else 0))

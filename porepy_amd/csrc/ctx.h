@@ -123,7 +123,9 @@ struct pfv_ctx_impl {
   bool have_mpsa_params = false, have_mpsa_numeric = false, have_mpsa_symbolic = false, have_mech_system = false;
   Buf<double> stiff;                 // [81][Nc]: stiff[(9*q + r)*Nc + c] = C_qr(c)
   Buf<double> cvol;                  // [nc] cell volumes (node-volume weights of the asymmetric part)
-  Buf<uint8_t> bc_dirbits, bc_neubits;
+  Buf<uint8_t> bc_dirbits, bc_neubits, bc_robbits;
+  Buf<double> mpsa_robw;             // [nd*nd][Nf] Robin weights
+  bool have_mpsa_robin = false;
   double mpsa_eta = 0.0;
   Buf<int32_t> cell_nnodes;          // [nc] distinct nodes of a cell (node-volume weights)
   Buf<int64_t> node_eptr, node_ebptr;  // [nn+1] offsets of the per-node expanded rows (cells / boundary faces)

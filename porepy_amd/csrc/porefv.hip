@@ -363,9 +363,32 @@ pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const do
     upload(h->cvol, cell_volumes, (size_t)h->nc, s);
     upload(h->bc_dirbits, bc_dir_bits, (size_t)h->nf, s);
     upload(h->bc_neubits, bc_neu_bits, (size_t)h->nf, s);
+    h->have_mpsa_robin = false;
     h->mpsa_eta = eta;
     h->have_mpsa_params = true;
     h->have_mpsa_numeric = h->have_mech_system = false;
+  });
+}
+
+pfv_status pfv_mpsa_set_robin(pfv_ctx* h, const uint8_t* bc_rob_bits, const double* robin_weight_ddn) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_mpsa_params, "pfv_mpsa_set_params first");
+    auto s = h->stream;
+    h->have_mpsa_robin = false;
+    if (!bc_rob_bits) return;
+    const size_t nf = (size_t)h->nf, n2 = (size_t)h->nd * h->nd;
+    upload(h->bc_robbits, bc_rob_bits, nf, s);
+    if (robin_weight_ddn) {
+      upload(h->mpsa_robw, robin_weight_ddn, n2 * nf, s);
+    } else {
+      std::vector<double> eye(n2 * nf, 0.0);
+      for (int i = 0; i < h->nd; ++i)
+        for (size_t f = 0; f < nf; ++f) eye[((size_t)h->nd * i + i) * nf + f] = 1.0;
+      upload(h->mpsa_robw, eye.data(), n2 * nf, s);
+    }
+    h->have_mpsa_robin = true;
+    h->have_mpsa_numeric = false;
+    h->have_mech_system = false;
   });
 }
 

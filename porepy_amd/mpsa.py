@@ -4,8 +4,8 @@ Operator API of ``pp.Mpsa`` (numerics/fv/mpsa.py:63-529): ``Mpsa(keyword)``, ``n
 ``discretize(sd, data)``, ``assemble_matrix_rhs(sd, data)``, four ``*_matrix_key`` attributes;
 parameters ``fourth_order_tensor``, ``bc`` (vectorial), ``bc_values`` ((nd, Nf) raveled "F"),
 ``source``, ``mpsa_eta``.  Unknown ordering is cell-major, component-minor (u[nd*c + a]).
-Covered: component-wise Dirichlet / Neumann conditions in the Cartesian basis.  Robin conditions,
-rotated bases and sub-face conditions raise NotImplementedError.
+Covered: component-wise Dirichlet / Neumann / Robin conditions in the Cartesian basis.  Rotated
+bases and sub-face conditions raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -58,8 +58,6 @@ class Mpsa:
         if np.asarray(bnd.is_dir).ndim != 2:
             # same failure mode as the reference (mpsa.py:658-659)
             raise AttributeError("MPSA must be given a vectorial boundary condition")
-        if np.any(getattr(bnd, "is_rob", False)):
-            raise NotImplementedError("Robin conditions are not covered by the device MPSA path yet")
         basis = getattr(bnd, "basis", None)
         if basis is not None and np.asarray(basis).ndim == 3:
             eye = np.eye(sd.dim)[:, :, None]
@@ -74,7 +72,9 @@ class Mpsa:
         elif np.asarray(eta).size != 1:
             raise NotImplementedError("per-sub-face eta is not covered for MPSA yet")
         ctx = self.context(sd)
-        ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta))
+        is_rob = getattr(bnd, "is_rob", None)
+        ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta),
+                            is_rob=is_rob, robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None)
         rows = None
         try:
             if partial:

@@ -41,6 +41,9 @@ class MpsaCase:
         self.grid["dim"] = int(self.grid["dim"])
         self.grid["name"] = str(self.grid["name"])
         self.bc = {"is_dir": z["bc_is_dir"], "is_neu": z["bc_is_neu"]}
+        if "bc_is_rob" in z.files:
+            self.bc["is_rob"] = z["bc_is_rob"]
+            self.bc["robin_weight"] = z["bc_robin_weight"]
         self.stiffness = z["stiffness"]
         self.bc_values = z["bc_values"]
         self.source = z["source"]

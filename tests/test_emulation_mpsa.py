@@ -60,7 +60,8 @@ def test_mpsa_rejects_what_it_does_not_cover(lib):
     with pytest.raises(AttributeError):
         pa.Mpsa("mechanics", library=lib).discretize(g, data)
     bcv = pa.BoundaryConditionVectorial(g)
-    bcv.is_rob[0, g.get_all_boundary_faces()[0]] = True
+    th = 0.3  # rotated boundary basis: not covered, refused
+    bcv.basis = np.tile(np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])[:, :, None], (1, 1, g.num_faces))
     data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bcv})
     with pytest.raises(NotImplementedError):
         pa.Mpsa("mechanics", library=lib).discretize(g, data)
