@@ -20,7 +20,7 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "partial_", "tilted_", "tpfa_"))]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "partial_", "tilted_", "tpfa_", "biot_"))]
 
 
 def mpsa_case_names():
@@ -206,3 +206,29 @@ class MpsaPartialCase:
                     spec["specified_" + kind] = v
             self.partial.append({"spec": spec, "active_faces": z[f"p{i}_active_faces"], "mats": mats(f"p{i}", MPSA_KEYS)})
         self.updated = mats("upd", ("stress", "bound_stress"))
+
+
+BIOT_KEYS = ("scalar_gradient", "displacement_divergence", "boundary_displacement_divergence", "mpsa_consistency",
+             "bound_displacement_pressure")
+
+
+class BiotCase:
+    """Poro-elastic coupling fixture made by oracle/gen_golden_biot.py from the reference's pp.Biot."""
+
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.grid["name"] = str(self.grid["name"])
+        self.bc = {"is_dir": z["bc_is_dir"], "is_neu": z["bc_is_neu"], "is_rob": z["bc_is_rob"],
+                   "robin_weight": z["bc_robin_weight"]}
+        self.stiffness = z["stiffness"]
+        self.alphas = {str(k): z[f"alpha_{k}"] for k in z["alpha_keys"]}
+
+        def mat(prefix):
+            shape = tuple(int(v) for v in z[prefix + "_shape"])
+            return sps.csr_matrix((z[prefix + "_data"], z[prefix + "_indices"], z[prefix + "_indptr"]), shape=shape)
+
+        self.ref = {k: {key: mat(f"ref_{k}__{key}") for key in self.alphas} for k in BIOT_KEYS}
+        self.ref_mech = {k: mat("ref_" + k) for k in ("stress", "bound_stress")}
