@@ -165,6 +165,26 @@ pfv_status pfv_get_rhs(pfv_ctx* h, double* b);
 /* y = M x for a produced matrix; host vectors (testing / flux post-processing) */
 pfv_status pfv_spmv(pfv_ctx* h, int which, const double* x, double* y);
 
+/* ---- Biot: coupling terms of the poro-elastic discretization (numerics/fv/biot.py:247-1135),
+ * computed from the same interaction-region inverse as MPSA.  One set of five matrices per
+ * coupling tensor ("scalar_vector_mappings" of the reference: Biot's alpha, thermal expansion...). */
+enum {
+  PFV_BIOT_SCALAR_GRADIENT = 0,                 /* (nd Nf x Nc)  */
+  PFV_BIOT_DISPLACEMENT_DIVERGENCE = 1,         /* (Nc x nd Nc)  */
+  PFV_BIOT_BOUNDARY_DISPLACEMENT_DIVERGENCE = 2, /* (Nc x nd Nf)  */
+  PFV_BIOT_CONSISTENCY = 3,                     /* (Nc x Nc), "mpsa_consistency" */
+  PFV_BIOT_BOUND_DISPLACEMENT_PRESSURE = 4,     /* (nd Nf x Nc)  */
+  PFV_BIOT_NUM_TERMS = 5
+};
+/* coupling tensors as SecondOrderTensor.values, shape (nalpha, 3, 3, Nc) C-order; nalpha = 0
+ * switches the coupling terms off.  Needs the grid and pfv_mpsa_set_params. */
+pfv_status pfv_biot_set_alphas(pfv_ctx* h, int nalpha, const double* alpha_k33n);
+/* Biot._local_discretization (biot.py:714-878): pfv_mpsa_discretize plus the coupling terms */
+pfv_status pfv_biot_discretize(pfv_ctx* h, uint32_t flags);
+pfv_status pfv_biot_matrix_info(pfv_ctx* h, int term, int64_t* nrows, int64_t* ncols, int64_t* nnz);
+pfv_status pfv_biot_get_matrix(pfv_ctx* h, int term, int key, int32_t* indptr, int32_t* indices,
+                               double* data);
+
 /* Hand an assembled system to the device solver: the caller of the hot path one level up,
  * SolutionStrategy.solve_linear_system (models/solution_strategy.py:830-884), holds the global
  * Jacobian as a scipy CSR matrix and the residual as a numpy vector.  CSR arrays (int32, any

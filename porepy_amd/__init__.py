@@ -11,6 +11,7 @@ from .grid import (CartGrid, Grid, StructuredTetrahedralGrid, StructuredTriangle
                    grid_to_raw, perturb_interior_nodes)
 from .mpfa import Mpfa, as_porepy_discretization, determine_eta
 from .mpsa import Mpsa
+from .biot import Biot
 from .partial import active_indices
 from .solvers import HipLinearSolver, solve_csr
 from .tpfa import Tpfa
@@ -22,5 +23,5 @@ __all__ = [
     "StructuredTetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "grid_from_raw", "Mpfa",
     "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition", "Mpsa",
     "FourthOrderTensor", "BoundaryConditionVectorial",
-    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa",
+    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa", "Biot",
 ]

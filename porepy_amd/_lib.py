@@ -36,6 +36,7 @@ EXPORTS = [
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
     "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin",
+    "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
 ]
 
 
@@ -92,6 +93,14 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpfa_discretize_faces.restype = C.c_int
     lib.pfv_mpsa_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int]
     lib.pfv_mpsa_discretize_faces.restype = C.c_int
+    lib.pfv_biot_set_alphas.argtypes = [_h, C.c_int, _dp]
+    lib.pfv_biot_set_alphas.restype = C.c_int
+    lib.pfv_biot_discretize.argtypes = [_h, C.c_uint32]
+    lib.pfv_biot_discretize.restype = C.c_int
+    lib.pfv_biot_matrix_info.argtypes = [_h, C.c_int, _lp, _lp, _lp]
+    lib.pfv_biot_matrix_info.restype = C.c_int
+    lib.pfv_biot_get_matrix.argtypes = [_h, C.c_int, C.c_int, _ip, _ip, _dp]
+    lib.pfv_biot_get_matrix.restype = C.c_int
     lib.pfv_mpsa_set_robin.argtypes = [_h, _up, _dp]
     lib.pfv_mpsa_set_robin.restype = C.c_int
     lib.pfv_reset_stream.argtypes = [_h]
@@ -270,6 +279,30 @@ class Context:
                 if W.shape != (self.nd, self.nd, self.nf):
                     raise ValueError("robin_weight must have shape (nd, nd, Nf)")
             self._check(self.lib.pfv_mpsa_set_robin(self._h, _ptr(rbits, _up), _ptr(W, _dp)))
+
+    # ---- Biot coupling terms ------------------------------------------------------------
+    def biot_set_alphas(self, alphas):
+        """alphas: sequence of (3, 3, Nc) coupling tensors (empty: switch the coupling terms off)."""
+        arr = np.ascontiguousarray(np.stack([_f64(a) for a in alphas]) if len(alphas) else np.zeros((0, 3, 3, self.nc)))
+        if arr.shape[1:] != (3, 3, self.nc):
+            raise ValueError(f"coupling tensors must have shape (3, 3, {self.nc})")
+        self._check(self.lib.pfv_biot_set_alphas(self._h, arr.shape[0], _ptr(arr, _dp) if arr.size else None))
+
+    def biot_discretize(self, rebuild_topology=False):
+        self._check(self.lib.pfv_biot_discretize(self._h, DISCR_REBUILD_TOPOLOGY if rebuild_topology else 0))
+        self._discretized_m = True
+
+    def biot_matrix(self, term: int, key: int):
+        import scipy.sparse as sps
+
+        r, c, z = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.pfv_biot_matrix_info(self._h, term, C.byref(r), C.byref(c), C.byref(z)))
+        indptr = np.empty(r.value + 1, dtype=np.int32)
+        indices = np.empty(z.value, dtype=np.int32)
+        data = np.empty(z.value, dtype=np.float64)
+        self._check(self.lib.pfv_biot_get_matrix(self._h, term, key, _ptr(indptr, _ip), _ptr(indices, _ip),
+                                                 _ptr(data, _dp)))
+        return sps.csr_matrix((data, indices, indptr), shape=(r.value, c.value))
 
     def mpsa_discretize(self, rebuild_topology=False):
         self._check(self.lib.pfv_mpsa_discretize(self._h, DISCR_REBUILD_TOPOLOGY if rebuild_topology else 0))

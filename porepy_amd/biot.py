@@ -1,0 +1,88 @@
+"""``Biot`` — the reference's poro-elastic discretization (numerics/fv/biot.py:39-712) on the
+device: the four MPSA matrices plus, per coupling tensor in ``scalar_vector_mappings``, the five
+coupling terms ``scalar_gradient``, ``displacement_divergence``,
+``boundary_displacement_divergence``, ``mpsa_consistency`` and ``bound_displacement_pressure``
+(dictionaries keyed like ``scalar_vector_mappings``), all from one pass of the interaction-region
+kernel.  Like the reference class it does not assemble; the poromechanics model combines the terms.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .mpfa import determine_eta
+from .mpsa import Mpsa
+from .mpsa import _KEYS as _MECH_KEYS
+from .params import DISCRETIZATION_MATRICES, PARAMETERS, SecondOrderTensor
+
+_TERMS = (
+    ("scalar_gradient", 0),
+    ("displacement_divergence", 1),
+    ("boundary_displacement_divergence", 2),
+    ("mpsa_consistency", 3),
+    ("bound_displacement_pressure", 4),
+)
+
+
+class Biot(Mpsa):
+    def __init__(self, keyword: str = "mechanics", device: int = 0, library=None):
+        super().__init__(keyword, device, library)
+        self.displacement_divergence_matrix_key = "displacement_divergence"
+        self.bound_displacement_divergence_matrix_key = "boundary_displacement_divergence"
+        self.scalar_gradient_matrix_key = "scalar_gradient"
+        self.consistency_matrix_key = "mpsa_consistency"
+        self.bound_pressure_matrix_key = "bound_displacement_pressure"
+
+    def ndof(self, sd) -> int:
+        return sd.num_cells * (1 + sd.dim)
+
+    def assemble_matrix_rhs(self, sd, data):
+        raise NotImplementedError("This class cannot be used for assembly (as in the reference, biot.py:125-149)")
+
+    def discretize(self, sd, data: dict) -> None:
+        pd = data[PARAMETERS][self.keyword]
+        md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
+        for key in ("specified_cells", "specified_faces", "specified_nodes"):
+            if pd.get(key) is not None:
+                raise NotImplementedError("partial discretization of the coupling terms is not covered")
+        C = pd["fourth_order_tensor"]
+        bnd = pd["bc"]
+        if np.asarray(bnd.is_dir).ndim != 2:
+            raise AttributeError("MPSA must be given a vectorial boundary condition")
+        basis = getattr(bnd, "basis", None)
+        if basis is not None and np.asarray(basis).ndim == 3 and not np.allclose(basis, np.eye(sd.dim)[:, :, None]):
+            raise NotImplementedError("rotated boundary bases are not covered yet")
+        mappings = pd["scalar_vector_mappings"]
+        keys = list(mappings.keys())
+        alphas = []
+        for k in keys:
+            a = mappings[k]
+            if isinstance(a, (float, int)):
+                a = SecondOrderTensor(float(a) * np.ones(sd.num_cells))
+            alphas.append(np.asarray(a.values, dtype=float))
+        eta = pd.get("mpsa_eta", None)
+        if eta is None:
+            eta = determine_eta(sd)
+        ctx = self.context(sd)
+        is_rob = getattr(bnd, "is_rob", None)
+        ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta), is_rob=is_rob,
+                            robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None)
+        ctx.biot_set_alphas(alphas)
+        try:
+            if alphas:
+                ctx.biot_discretize()
+            else:
+                ctx.mpsa_discretize()
+        except _lib.PorefvError as e:
+            if e.status == 1:
+                raise ValueError("Error in inversion of local linear systems") from e
+            if e.status == 2:
+                raise AssertionError(e.message) from e
+            raise
+        for name, which in _MECH_KEYS:
+            md[name] = ctx.matrix(which)
+        for name, term in _TERMS:
+            md[name] = {k: ctx.biot_matrix(term, i) for i, k in enumerate(keys)}
+
+    def update_discretization(self, sd, data: dict) -> None:
+        self.discretize(sd, data)

@@ -131,6 +131,16 @@ struct pfv_ctx_impl {
   Buf<int64_t> node_eptr, node_ebptr;  // [nn+1] offsets of the per-node expanded rows (cells / boundary faces)
   Buf<double> Es, Et, Esb, Etb;      // per node: (nd*nsf) x (nd*deg) stress / trace rows; x (nd*nb) boundary
   CsrPattern pat_stress, pat_bstress, pat_Am;
+  // ---- Biot coupling terms (biot.inc) ------------------------------------------------
+  int biot_nalpha = 0;               // coupling tensors set by pfv_biot_set_alphas
+  Buf<double> biot_alpha;            // [nalpha][9][Nc]
+  bool have_biot_symbolic = false, have_biot_numeric = false;
+  Buf<int32_t> cn_ptr, cn_idx;       // cell -> distinct nodes (CSR)
+  Buf<int64_t> node_dptr, node_dbptr, node_cptr;  // per-node offsets of the divergence rows
+  int64_t biot_tot_p = 0, biot_tot_d = 0, biot_tot_db = 0, biot_tot_c = 0;
+  Buf<double> bEsp, bEtp, bDD, bBDD, bCONS;       // per node and key, see mpsa.inc
+  CsrPattern pat_sg, pat_dd, pat_bdd;  // (nd Nf x Nc), (Nc x nd Nc), (Nc x nd Nf); consistency uses pat_A
+  Buf<double> biot_val[5 * 8];         // values: term-major (PFV_BIOT_* order), then key (<= 8 keys)
   CsrPattern pat_user;               // pfv_set_system
   CsrPattern pat_bpf;                // TPFA: bound_pressure_face (diagonal of the Dirichlet / Neumann faces)
   bool rows_complete_m = false;      // every row of the four MPSA matrices holds a discretization

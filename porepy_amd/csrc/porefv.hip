@@ -11,6 +11,7 @@
 #include "linalg.inc"
 #include "mpsa.inc"
 #include "tpfa.inc"
+#include "biot.inc"
 
 namespace pfv {
 pfv_ctx_impl::pfv_ctx_impl() = default;
@@ -412,7 +413,9 @@ pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags) {
       tm.start(s);
       pfv::mpsa_symbolic(*h);
       h->stats.symbolic_ms += tm.stop(s);
+      h->have_biot_symbolic = false;
     }
+    if (h->biot_nalpha > 0 && !h->have_biot_symbolic) pfv::biot_symbolic(*h);
     tm.start(s);
     pfv::mpsa_run_node_kernel(*h);
     h->stats.node_ms = tm.stop(s);
@@ -445,7 +448,11 @@ pfv_status pfv_mpsa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces
       h->have_mpsa_symbolic = false;
       h->have_numeric = h->have_system = false;
     }
-    if (!h->have_mpsa_symbolic) pfv::mpsa_symbolic(*h);
+    if (!h->have_mpsa_symbolic) {
+      pfv::mpsa_symbolic(*h);
+      h->have_biot_symbolic = false;
+    }
+    if (h->biot_nalpha > 0 && !h->have_biot_symbolic) pfv::biot_symbolic(*h);
     int32_t* sub = h->face_subset.ensure(std::max<int64_t>(n_faces, 1));
     uint8_t* act = h->node_active.ensure(h->nn);
     pfv::be_h2d(sub, faces, sizeof(int32_t) * (size_t)n_faces, s);
@@ -473,6 +480,88 @@ pfv_status pfv_mpsa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces
     h->have_mpsa_numeric = true;
     h->have_mech_system = false;
     h->filled[PFV_MAT_MECH_SYSTEM] = false;
+  });
+}
+
+pfv_status pfv_biot_set_alphas(pfv_ctx* h, int nalpha, const double* alpha_k33n) {
+  return guarded(h, [&] {
+    require(h->have_grid, "pfv_set_grid must be called first");
+    require(nalpha >= 0 && nalpha <= 8 && (nalpha == 0 || alpha_k33n), "bad coupling tensors");
+    const bool layout_change = (nalpha > 0) != (h->biot_nalpha > 0) || nalpha != h->biot_nalpha;
+    h->biot_nalpha = nalpha;
+    if (nalpha > 0) upload(h->biot_alpha, alpha_k33n, (size_t)nalpha * 9 * (size_t)h->nc, h->stream);
+    if (layout_change) {
+      h->have_mpsa_symbolic = false;  // LDS sizing of the node kernel depends on it
+      h->have_biot_symbolic = false;
+    }
+    h->have_biot_numeric = false;
+  });
+}
+
+pfv_status pfv_biot_discretize(pfv_ctx* h, uint32_t flags) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_mpsa_params, "grid and MPSA parameters must be set before discretize");
+    require(h->biot_nalpha > 0, "pfv_biot_set_alphas first");
+    auto s = h->stream;
+    pfv::Timer tm;
+    if (!h->have_topology || !h->have_symbolic || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
+      tm.start(s);
+      pfv::build_topology(*h);
+      h->stats.topology_ms = tm.stop(s);
+      tm.start(s);
+      pfv::build_symbolic(*h);
+      h->stats.symbolic_ms = tm.stop(s);
+      h->tpfa_mode = false;
+      h->have_mpsa_symbolic = h->have_biot_symbolic = false;
+      h->have_numeric = h->have_system = false;
+    }
+    if (!h->have_mpsa_symbolic) {
+      pfv::mpsa_symbolic(*h);
+      h->have_biot_symbolic = false;
+    }
+    if (!h->have_biot_symbolic) pfv::biot_symbolic(*h);
+    tm.start(s);
+    pfv::mpsa_run_node_kernel(*h);
+    h->stats.node_ms = tm.stop(s);
+    tm.start(s);
+    pfv::mpsa_run_face_kernel(*h);
+    for (int ka = 0; ka < h->biot_nalpha; ++ka) {
+      pfv::biot_run_face_kernel(*h, ka);
+      pfv::biot_run_cell_kernel(*h, ka);
+    }
+    h->stats.face_ms = tm.stop(s);
+    h->have_mpsa_numeric = true;
+    h->rows_complete_m = true;
+    h->have_biot_numeric = true;
+    h->have_mech_system = false;
+    h->filled[PFV_MAT_MECH_SYSTEM] = false;
+  });
+}
+
+pfv_status pfv_biot_matrix_info(pfv_ctx* h, int term, int64_t* nrows, int64_t* ncols, int64_t* nnz) {
+  return guarded(h, [&] {
+    require(term >= 0 && term < PFV_BIOT_NUM_TERMS, "bad term");
+    require(h->have_biot_symbolic, "pfv_biot_discretize first");
+    const pfv::CsrPattern& P = pfv::biot_pattern(*h, term);
+    if (nrows) *nrows = P.nrows;
+    if (ncols) *ncols = P.ncols;
+    if (nnz) *nnz = P.nnz;
+  });
+}
+
+pfv_status pfv_biot_get_matrix(pfv_ctx* h, int term, int key, int32_t* indptr, int32_t* indices, double* data) {
+  return guarded(h, [&] {
+    require(term >= 0 && term < PFV_BIOT_NUM_TERMS, "bad term");
+    require(h->have_biot_symbolic, "pfv_biot_discretize first");
+    require(key >= 0 && key < h->biot_nalpha, "bad coupling key");
+    const pfv::CsrPattern& P = pfv::biot_pattern(*h, term);
+    auto s = h->stream;
+    if (indptr) be_d2h(indptr, P.indptr.p, sizeof(int32_t) * (size_t)(P.nrows + 1), s);
+    if (indices) be_d2h(indices, P.indices.p, sizeof(int32_t) * (size_t)P.nnz, s);
+    if (data) {
+      require(h->have_biot_numeric, "pfv_biot_discretize first");
+      be_d2h(data, h->biot_val[(size_t)term * h->biot_nalpha + key].p, sizeof(double) * (size_t)P.nnz, s);
+    }
   });
 }
 

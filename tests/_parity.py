@@ -11,7 +11,7 @@ import scipy.sparse.linalg as spla
 
 import porepy_amd as pa
 from oracle import mpfa_oracle as mo
-from tests._golden import MPSA_KEYS, MpsaPartialCase, ALL_KEYS, Case, PartialCase, TiltedCase, check_pattern, rel_max_err
+from tests._golden import BIOT_KEYS, BiotCase, MPSA_KEYS, MpsaPartialCase, ALL_KEYS, Case, PartialCase, TiltedCase, check_pattern, rel_max_err
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMUL_SO = os.path.join(ROOT, "oracle", "_build", "libporefv_emul.so")
@@ -541,3 +541,30 @@ def amg_preconditioner(lib, g, seed=2, hetero_sigma=0.5):
     st = d.context(g).stats()
     assert st["amg_levels"] >= 2 and 1.0 < st["amg_operator_complexity"] < 2.0
     return out, ij["iterations"], st
+
+
+def check_biot_case(lib, name: str):
+    """Biot operator class: MPSA matrices + the five coupling terms per coupling tensor against the
+    oracle (exact pattern) and against what the reference's pp.Biot produced."""
+    c = BiotCase(name)
+    g = pa.grid_from_raw(c.grid)
+    bc = pa.BoundaryConditionVectorial(g)
+    bc.is_dir, bc.is_neu, bc.is_rob = c.bc["is_dir"].copy(), c.bc["is_neu"].copy(), c.bc["is_rob"].copy()
+    bc.robin_weight = c.bc["robin_weight"]
+    C = type("C", (), {"values": c.stiffness})()
+    maps = {k: type("A", (), {"values": v})() for k, v in c.alphas.items()}
+    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "scalar_vector_mappings": maps})
+    d = pa.Biot("mechanics", library=lib)
+    d.discretize(g, data)
+    md = data[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    ora = so.discretize(c.grid, c.stiffness, c.bc, alphas=c.alphas)
+    for k in ("stress", "bound_stress"):
+        assert rel_max_err(md[k], c.ref_mech[k]) < TOL, (name, k)
+    for k in BIOT_KEYS:
+        for key in c.alphas:
+            M = md[k][key]
+            assert M.shape == c.ref[k][key].shape, (name, k, key)
+            assert M.indices.dtype == np.int32 and M.has_sorted_indices
+            assert np.array_equal(M.indptr, ora[k][key].indptr) and np.array_equal(M.indices, ora[k][key].indices), (name, k, key)
+            assert rel_max_err(M, ora[k][key]) < TOL, (name, k, key)
+            assert rel_max_err(M, c.ref[k][key]) < TOL, (name, k, key)

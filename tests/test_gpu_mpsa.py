@@ -69,3 +69,8 @@ def test_amg_block_preconditioner_for_mechanics(lib):
     info = P.mpsa_uniaxial_exact(lib, g, tol=1e-9, precond="amg")
     base = P.mpsa_uniaxial_exact(lib, g, tol=1e-9)
     assert info["iterations"] * 2 < base["iterations"], (info, base)
+
+
+@pytest.mark.parametrize("name", ["biot_tri2d_3x3_mixed", "biot_cart2d_3x2_dir", "biot_tet_2x2x2_mixed"])
+def test_biot_coupling_terms(lib, name):
+    P.check_biot_case(lib, name)
