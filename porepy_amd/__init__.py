@@ -10,8 +10,8 @@ from ._lib import Context, PorefvError
 from .grid import (CartGrid, Grid, StructuredTetrahedralGrid, StructuredTriangleGrid, grid_from_raw,
                    grid_to_raw, perturb_interior_nodes)
 from .mpfa import Mpfa, as_porepy_discretization, determine_eta
-from .mpsa import Mpsa
-from .biot import Biot
+from .mpsa import Mpsa, as_porepy_mpsa
+from .biot import Biot, as_porepy_biot
 from .partial import active_indices
 from .solvers import HipLinearSolver, solve_csr
 from .tpfa import Tpfa
@@ -23,5 +23,5 @@ __all__ = [
     "StructuredTetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "grid_from_raw", "Mpfa",
     "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition", "Mpsa",
     "FourthOrderTensor", "BoundaryConditionVectorial",
-    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa", "Biot",
+    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa", "Biot", "as_porepy_mpsa", "as_porepy_biot",
 ]

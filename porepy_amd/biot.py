@@ -86,3 +86,29 @@ class Biot(Mpsa):
 
     def update_discretization(self, sd, data: dict) -> None:
         self.discretize(sd, data)
+
+
+def as_porepy_biot(device: int = 0, library=None):
+    """Subclass of the reference's ``pp.Biot`` running on the MI355X (``pp.Biot = as_porepy_biot()``;
+    ``pp.ad.BiotAd`` resolves ``pp.Biot`` at call time, numerics/ad/discretizations.py:87-131)."""
+    import porepy as pp  # the reference; absent on the GPU box
+
+    _device, _library = device, library
+    _Ref = pp.Biot
+
+    class HipBiot(_Ref):  # type: ignore[misc]
+        def __init__(self, keyword: str = "mechanics"):
+            _Ref.__init__(self, keyword)
+            self._hip = Biot(keyword, _device, _library)
+
+        def discretize(self, sd, sd_data):
+            if sd.dim < 2:
+                return _Ref.discretize(self, sd, sd_data)
+            return self._hip.discretize(sd, sd_data)
+
+        def update_discretization(self, sd, sd_data):
+            if sd.dim < 2:
+                return _Ref.update_discretization(self, sd, sd_data)
+            return self._hip.update_discretization(sd, sd_data)
+
+    return HipBiot

@@ -155,3 +155,35 @@ class Mpsa:
         ctx = self._assemble(sd, data)
         return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, n=sd.dim * sd.num_cells, restart=restart,
                          precond=precond)
+
+
+def as_porepy_mpsa(device: int = 0, library=None):
+    """Subclass of the reference's ``pp.Mpsa`` whose hot path runs on the MI355X; rebind with
+    ``pp.Mpsa = porepy_amd.as_porepy_mpsa()`` before the model is built (``pp.ad.MpsaAd`` resolves
+    ``pp.Mpsa`` at call time, numerics/ad/discretizations.py:134-150)."""
+    import porepy as pp  # the reference; absent on the GPU box
+
+    _device, _library = device, library
+    _Ref = pp.Mpsa
+
+    class HipMpsa(_Ref):  # type: ignore[misc]
+        def __init__(self, keyword: str):
+            _Ref.__init__(self, keyword)
+            self._hip = Mpsa(keyword, _device, _library)
+
+        def discretize(self, sd, data):
+            if sd.dim < 2:
+                return _Ref.discretize(self, sd, data)
+            return self._hip.discretize(sd, data)
+
+        def update_discretization(self, sd, data):
+            if sd.dim < 2:
+                return _Ref.update_discretization(self, sd, data)
+            return self._hip.update_discretization(sd, data)
+
+        def assemble_matrix_rhs(self, sd, data):
+            if sd.dim < 2:
+                return _Ref.assemble_matrix_rhs(self, sd, data)
+            return self._hip.assemble_matrix_rhs(sd, data)
+
+    return HipMpsa

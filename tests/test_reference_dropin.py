@@ -27,3 +27,21 @@ def test_single_phase_flow_model_with_rebound_mpfa():
     assert out["A_rel_err"] < 1e-10  # (the final residual vector is round-off in both runs)
     assert out["p_rel_err_hip_solver"] < 1e-10 and out["hip_solver_iterations"] > 0
     assert abs(out["p_sum_ref"] - 8750.0) < 1e-6  # config C1 of the reference
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference PorePy not present")
+def test_momentum_balance_and_poromechanics_models_with_rebound_mpsa_biot():
+    """pp.Mpsa, pp.Biot and pp.Mpfa rebound under the reference's own MomentumBalance and
+    Poromechanics models: displacement / pressure and the Jacobian reproduce the untouched runs."""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "oracle", "shim"), REF, ROOT])
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dropin_mech_script.py")], env=env, cwd="/tmp",
+                       capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, r.stderr[-2000:]
+    out = json.loads(line[-1][7:])
+    assert out["calls"]["mpsa"] >= 1 and out["calls"]["biot"] >= 1
+    assert out["mech_dofs"] == 72 and out["poro_dofs"] == 108
+    assert out["mech_x_rel_err"] < 1e-10 and out["mech_A_rel_err"] < 1e-10
+    assert out["poro_x_rel_err"] < 1e-10 and out["poro_A_rel_err"] < 1e-10
