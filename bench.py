@@ -92,6 +92,55 @@ def bench_config_c2(pa, device_index: int, rtol: float, precond: str, steps: int
                                              "solve_ms")}}
 
 
+def bench_config_c4(pa, device_index: int, rtol: float, precond: str, steps: int = 2):
+    """BASELINE.json configs[3] on one GPU: MPSA linear elasticity, 511 104 tetrahedra ([44]^3 lattice,
+    1.53 M dofs), mu = lambda = 1, rollers on the low faces, unit traction on top; the
+    exact solution is the uniaxial field u = (nu x / E, nu y / E, -z / E)."""
+    n = 44
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.2 / n)
+    nc, nf = g.num_cells, g.num_faces
+    C = pa.FourthOrderTensor(np.ones(nc), np.ones(nc))
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    fc = g.face_centers
+    for axis in range(3):
+        roll = bf[fc[axis, bf] < 1e-9]
+        bc.is_dir[axis, roll] = True
+        bc.is_neu[axis, roll] = False
+    bv = np.zeros((3, nf))
+    top = bf[fc[2, bf] > 1 - 1e-9]
+    bv[2, top] = -g.face_areas[top]
+    bvf = bv.ravel("F")
+    ctx = pa.Context(device_index)
+    ctx.set_grid(pa.grid_to_raw(g))
+    ctx.mpsa_set_params(C.values, g.cell_volumes, bc.is_dir, bc.is_neu, 1.0 / 3.0)
+
+    def step():
+        ctx.mpsa_discretize(rebuild_topology=True)
+        ctx.mpsa_assemble(bvf, None)
+        return ctx.solve("bicgstab", rtol=rtol, maxit=50000, n=3 * nc, raise_on_fail=False, precond=precond)
+
+    u, info = step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        u, info = step()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    st = ctx.stats()
+    cc = g.cell_centers
+    E, nu = 2.5, 0.25
+    err = float(np.max(np.abs(u.reshape(3, -1, order="F") - np.vstack((nu * cc[0] / E, nu * cc[1] / E, -cc[2] / E)))))
+    return {"workload": "BASELINE configs[3] on 1 GPU: MPSA elasticity, 511104 tetrahedra, 3 dof/cell, rollers + top traction",
+            "value": nc / dt, "unit": "cells/s", "ms_per_step": 1e3 * dt, "steps": steps, "dofs": 3 * nc,
+            "iterations": info["iterations"], "krylov": "bicgstab+" + precond,
+            "max_abs_error_vs_exact_uniaxial_field": err,
+            "phases_ms": {k: st[k] for k in ("topology_ms", "symbolic_ms", "node_ms", "face_ms", "assemble_ms",
+                                             "solve_ms")}}
+
+
 def _hash_normal(gid: np.ndarray, salt: int) -> np.ndarray:
     """Deterministic N(0,1) per global id (splitmix64 hash + Box-Muller): the same field on every
     rank without materialising a global array."""
@@ -325,7 +374,7 @@ def main():
                 "cells_per_s_assembly_only": nloc / (asm_ms * 1e-3)}
 
     cpu = None
-    c2 = None
+    c2 = c4 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_n_side)
     if rank == 0 and world == 1 and not args.force_sharded and args.n_side == 69:
@@ -333,6 +382,10 @@ def main():
             c2 = bench_config_c2(pa, local_rank, args.rtol, args.precond)
         except Exception as e:  # secondary line only
             c2 = {"error": repr(e)}
+        try:
+            c4 = bench_config_c4(pa, local_rank, args.rtol, args.precond)
+        except Exception as e:  # secondary line only
+            c4 = {"error": repr(e)}
 
     if rank == 0:
         res_true = None
@@ -363,7 +416,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} z-slab subdomains (1 lattice layer of halo cells recomputed per cut), assembly "
                        "without collectives, BiCGStab with RCCL point-to-point halo exchange + fused all-reduces"},
-            "roofline": roofline, "assembly": assembly, "cpu_baseline": cpu, "config_c2": c2,
+            "roofline": roofline, "assembly": assembly, "cpu_baseline": cpu, "config_c2": c2, "config_c4": c4,
         }
         if args.phases:
             print(json.dumps(st, indent=1), file=sys.stderr)

@@ -241,7 +241,8 @@ pfv_status pfv_spmv_device(pfv_ctx* h, int which, const double* d_x, double* d_y
 pfv_status pfv_spmv_device_rows(pfv_ctx* h, int which, int64_t nrows, const double* d_x, double* d_y);
 pfv_status pfv_get_device_rhs(pfv_ctx* h, double** d_b, double** d_diag);
 /* device-to-device copy of an internal vector into caller memory (e.g. a torch tensor):
- * which = 0 right-hand side b (Nc), 1 diagonal of A (Nc) */
+ * which = 0 right-hand side, 1 diagonal of the system assembled last (Nc entries for flow,
+ * nd Nc for mechanics) */
 pfv_status pfv_copy_device_vector(pfv_ctx* h, int which, double* d_dst, int64_t count);
 /* Block preconditioner of a sharded solve: aggregation-AMG hierarchy of the leading
  * n_own x n_own block of the active system (a rank's owned cells; couplings to halo columns are

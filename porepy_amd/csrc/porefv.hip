@@ -653,9 +653,9 @@ pfv_status pfv_spmv_device_rows(pfv_ctx* h, int which, int64_t nrows, const doub
 
 pfv_status pfv_copy_device_vector(pfv_ctx* h, int which, double* d_dst, int64_t count) {
   return guarded(h, [&] {
-    require(h->have_system && d_dst && count >= 0 && count <= h->nc, "bad argument / assemble first");
+    require(h->active.valid && d_dst && count >= 0 && count <= h->active.n, "bad argument / assemble first");
     require(which == 0 || which == 1, "which must be 0 (rhs) or 1 (diagonal)");
-    pfv::be_d2d(d_dst, which == 0 ? h->rhs.p : h->diag.p, sizeof(double) * (size_t)count, h->stream);
+    pfv::be_d2d(d_dst, which == 0 ? h->active.rhs : h->active.diag, sizeof(double) * (size_t)count, h->stream);
   });
 }
 

@@ -156,6 +156,17 @@ class HaloPlan:
         self.recv = {k: v.to(device) for k, v in self.recv.items()}
         return self
 
+    def expand(self, bs: int):
+        """Exchange bs consecutive unknowns per cell (cell-major, component-minor numbering)."""
+        if bs > 1:
+            import torch
+
+            off = torch.arange(bs, dtype=torch.int64)
+            self.send = {k: (v[:, None] * bs + off[None, :]).reshape(-1) for k, v in self.send.items()}
+            self.recv = {k: (v[:, None] * bs + off[None, :]).reshape(-1) for k, v in self.recv.items()}
+            self.bytes_per_exchange *= bs
+        return self
+
     def exchange(self, x_full):
         """Fill the halo entries of x_full (owned entries must be current)."""
         if self.world == 1 or (not self.send and not self.recv):
@@ -192,11 +203,17 @@ class ShardedMpfa:
         self.dist = dist
         self.ctx = _lib.Context(local_device_index, library)
         self.ctx.set_grid(lp.raw)
-        self.n_own = lp.n_own
-        self.n_loc = lp.raw["cell_centers"].shape[1]
-        self.plan = HaloPlan(lp, dist).to(self.device)
+        self.bs = self._dofs_per_cell(lp)
+        self.n_own = lp.n_own * self.bs        # unknowns of owned cells
+        self.n_loc = lp.raw["cell_centers"].shape[1] * self.bs
+        self.plan = HaloPlan(lp, dist).expand(self.bs).to(self.device)
         self._b = self._diag = None
         self._amg_ready = False
+
+    system_matrix = _lib.MAT_SYSTEM
+
+    def _dofs_per_cell(self, lp) -> int:
+        return 1
 
     # boundary flags of the local grid: true boundary faces keep theirs; faces that are one-sided
     # only because the neighbour is outside the local grid are Neumann (they never touch a node of
@@ -212,8 +229,11 @@ class ShardedMpfa:
         self.ctx.discretize(rebuild_topology=rebuild_topology, skip_vector_source=skip_vector_source)
 
     def assemble(self, bc_values_local, source_local=None):
-        torch = self.torch
         self.ctx.assemble(bc_values_local, None, source_local)
+        self._fetch_system()
+
+    def _fetch_system(self):
+        torch = self.torch
         self._amg_ready = False  # the matrix may have changed
         self._b = torch.empty(self.n_loc, dtype=torch.float64, device=self.device)
         self._diag = torch.empty(self.n_loc, dtype=torch.float64, device=self.device)
@@ -232,7 +252,7 @@ class ShardedMpfa:
 
     def _spmv_owned(self, x_full, out_owned):
         self.plan.exchange(x_full)
-        self.ctx.spmv_device_rows(_lib.MAT_SYSTEM, self.n_own, x_full.data_ptr(), out_owned.data_ptr())
+        self.ctx.spmv_device_rows(self.system_matrix, self.n_own, x_full.data_ptr(), out_owned.data_ptr())
 
     def solve(self, method: str = "bicgstab", rtol: float = 1e-10, maxit: int = 20000, check_every: int = 10,
               precond: str = "jacobi"):
@@ -338,5 +358,35 @@ class ShardedMpfa:
 
     def owned_system_rows(self):
         """(A rows of owned cells as scipy csr over local columns, b_owned) — for tests."""
-        A = self.ctx.matrix(_lib.MAT_SYSTEM)
-        return A[: self.n_own], self.ctx.rhs()[: self.n_own]
+        A = self.ctx.matrix(self.system_matrix)
+        return A[: self.n_own], self.ctx.active_rhs(self.n_loc)[: self.n_own]
+
+
+class ShardedMpsa(ShardedMpfa):
+    """MPSA assembly of one rank's subdomain + the distributed solve of the elasticity system
+    (nd unknowns per cell, cell-major; same halo plan, nd values per exchanged cell; the block
+    preconditioner aggregates cells and keeps the components apart)."""
+
+    system_matrix = _lib.MAT_MECH_SYSTEM
+
+    def _dofs_per_cell(self, lp) -> int:
+        return int(lp.raw["dim"])
+
+    def local_bc(self, is_dir_true, is_neu_true):
+        """Component-wise flags of the local grid: faces that are one-sided only because the
+        neighbour cell lies outside the local grid become Neumann (they never touch a node of an
+        owned cell)."""
+        d, n = np.array(is_dir_true, dtype=bool), np.array(is_neu_true, dtype=bool)
+        d[:, self.lp.artificial_boundary] = False
+        n[:, self.lp.artificial_boundary] = True
+        return d, n
+
+    def discretize(self, stiffness_local, is_dir_local, is_neu_local, eta=0.0, rebuild_topology=False,
+                   is_rob_local=None, robin_weight_local=None):
+        self.ctx.mpsa_set_params(stiffness_local, self.lp.raw["cell_volumes"], is_dir_local, is_neu_local, eta,
+                                 is_rob=is_rob_local, robin_weight=robin_weight_local)
+        self.ctx.mpsa_discretize(rebuild_topology=rebuild_topology)
+
+    def assemble(self, bc_values_local, source_local=None):
+        self.ctx.mpsa_assemble(bc_values_local, source_local)
+        self._fetch_system()

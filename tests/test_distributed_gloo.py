@@ -171,3 +171,73 @@ def test_bench_slab_decomposition_matches_single_domain(tmp_path):
         assert np.linalg.norm(o["x"] - want) <= 1e-9 * np.linalg.norm(x_ref)
         total += o["gid"].size
     assert total == lp.n_own
+
+
+def _mech_problem():
+    g = pa.StructuredTetrahedralGrid([3, 3, 4], [1, 1, 1.2])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.04, seed=4)
+    nc = g.num_cells
+    rng = np.random.default_rng(9)
+    C = pa.FourthOrderTensor(1 + rng.random(nc), 1 + rng.random(nc))
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    low = bf[g.face_centers[0, bf] < 1e-9]   # clamp a face that every z-slab touches
+    bc.is_dir[:, low] = True
+    bc.is_neu[:, low] = False
+    bv = np.zeros((3, g.num_faces))
+    top = bf[g.face_centers[2, bf] > 1.2 - 1e-9]
+    bv[2, top] = -g.face_areas[top]
+    bv[0, top] = 0.3 * g.face_areas[top]
+    return g, C, bc, bv
+
+
+def _mech_worker(rank, world, port, out, precond):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = P.emulation_library()
+        g, C, bc, bv = _mech_problem()
+        raw = pa.grid_to_raw(g)
+        owner = D.partition_slabs(raw["cell_centers"], world, axis=2)
+        lp = D.extract_subdomain(raw, owner, rank)
+        sh = D.ShardedMpsa(lp, device="cpu", library=lib, dist=dist)
+        is_dir, is_neu = sh.local_bc(bc.is_dir[:, lp.face_gid], bc.is_neu[:, lp.face_gid])
+        sh.discretize(C.values[:, :, lp.cell_gid], is_dir, is_neu, pa.determine_eta(g))
+        sh.assemble(bv[:, lp.face_gid].ravel("F"))
+        x, info = sh.solve("bicgstab", rtol=1e-12, maxit=5000, check_every=1, precond=precond)
+        torch.save({"gid": lp.cell_gid, "n_own": lp.n_own, "x": x.numpy(), "info": info},
+                   os.path.join(out, f"m{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precond", ["jacobi", "amg"])
+def test_two_rank_sharded_mpsa(tmp_path, precond):
+    """Elasticity (3 unknowns per cell) sharded over two ranks: halo exchange of cell blocks, block
+    AMG per rank; the owned displacements equal the single-domain solution."""
+    import torch
+    import torch.multiprocessing as mp
+
+    world = 2
+    P.emulation_library()
+    mp.spawn(_mech_worker, args=(world, _free_port(), str(tmp_path), precond), nprocs=world, join=True)
+    lib = P.emulation_library()
+    g, C, bc, bv = _mech_problem()
+    data = pa.initialize_data({}, "mech", {"fourth_order_tensor": C, "bc": bc, "bc_values": bv.ravel("F")})
+    d = pa.Mpsa("mech", library=lib)
+    d.discretize(g, data)
+    A, b = d.assemble_matrix_rhs(g, data)
+    x_ref = spla.spsolve(A.tocsc(), b).reshape(-1, 3)
+    seen = np.zeros(g.num_cells, dtype=bool)
+    for r in range(world):
+        o = torch.load(os.path.join(str(tmp_path), f"m{r}.pt"), weights_only=False)
+        own = o["gid"][: o["n_own"]]
+        seen[own] = True
+        assert o["info"]["converged"]
+        assert np.linalg.norm(o["x"].reshape(-1, 3) - x_ref[own]) <= 1e-8 * np.linalg.norm(x_ref)
+    assert seen.all()
