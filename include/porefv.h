@@ -215,8 +215,12 @@ pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const do
  * .robin_weight, params/bc.py:222-322; rows of numerics/fv/mpsa.py:1381-1459): bit c of
  * bc_rob_bits[f] = component c of face f is Robin; robin_weight_ddn = weights W[i][a][f], shape
  * (nd, nd, Nf) C-order (NULL = identity).  Call after pfv_mpsa_set_params (which clears them);
- * bc_rob_bits = NULL removes them.  Cartesian basis only. */
+ * bc_rob_bits = NULL removes them. */
 pfv_status pfv_mpsa_set_robin(pfv_ctx* h, const uint8_t* bc_rob_bits, const double* robin_weight_ddn);
+/* face-wise basis in which the boundary conditions are given (BoundaryConditionVectorial.basis,
+ * shape (nd, nd, Nf) C-order; row k = the k-th direction); NULL = Cartesian.  Call after
+ * pfv_mpsa_set_params (which resets it). */
+pfv_status pfv_mpsa_set_basis(pfv_ctx* h, const double* basis_ddn);
 
 /* Mpsa._stress_discretization (numerics/fv/mpsa.py:531-782) on the device; fills matrices 7-10 */
 pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags);

@@ -35,7 +35,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
 ]
 
@@ -101,6 +101,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_biot_matrix_info.restype = C.c_int
     lib.pfv_biot_get_matrix.argtypes = [_h, C.c_int, C.c_int, _ip, _ip, _dp]
     lib.pfv_biot_get_matrix.restype = C.c_int
+    lib.pfv_mpsa_set_basis.argtypes = [_h, _dp]
+    lib.pfv_mpsa_set_basis.restype = C.c_int
     lib.pfv_mpsa_set_robin.argtypes = [_h, _up, _dp]
     lib.pfv_mpsa_set_robin.restype = C.c_int
     lib.pfv_reset_stream.argtypes = [_h]
@@ -255,7 +257,8 @@ class Context:
                                                  _ptr(rw, _dp), float(eta), _ptr(es, _dp)))
 
     # ---- MPSA ----------------------------------------------------------------------
-    def mpsa_set_params(self, stiffness, cell_volumes, is_dir, is_neu, eta=0.0, is_rob=None, robin_weight=None):
+    def mpsa_set_params(self, stiffness, cell_volumes, is_dir, is_neu, eta=0.0, is_rob=None, robin_weight=None,
+                        basis=None):
         C9 = _f64(stiffness)
         if C9.shape != (9, 9, self.nc):
             raise ValueError(f"stiffness must have shape (9, 9, {self.nc})")
@@ -279,6 +282,12 @@ class Context:
                 if W.shape != (self.nd, self.nd, self.nf):
                     raise ValueError("robin_weight must have shape (nd, nd, Nf)")
             self._check(self.lib.pfv_mpsa_set_robin(self._h, _ptr(rbits, _up), _ptr(W, _dp)))
+        if basis is not None:
+            B = _f64(basis)
+            if B.shape != (self.nd, self.nd, self.nf):
+                raise ValueError("basis must have shape (nd, nd, Nf)")
+            if not np.array_equal(B, np.tile(np.eye(self.nd)[:, :, None], (1, 1, self.nf))):
+                self._check(self.lib.pfv_mpsa_set_basis(self._h, _ptr(B, _dp)))
 
     # ---- Biot coupling terms ------------------------------------------------------------
     def biot_set_alphas(self, alphas):

@@ -50,8 +50,8 @@ class Biot(Mpsa):
         if np.asarray(bnd.is_dir).ndim != 2:
             raise AttributeError("MPSA must be given a vectorial boundary condition")
         basis = getattr(bnd, "basis", None)
-        if basis is not None and np.asarray(basis).ndim == 3 and not np.allclose(basis, np.eye(sd.dim)[:, :, None]):
-            raise NotImplementedError("rotated boundary bases are not covered yet")
+        if basis is not None and np.asarray(basis).ndim != 3:
+            basis = None
         mappings = pd["scalar_vector_mappings"]
         keys = list(mappings.keys())
         alphas = []
@@ -66,7 +66,8 @@ class Biot(Mpsa):
         ctx = self.context(sd)
         is_rob = getattr(bnd, "is_rob", None)
         ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta), is_rob=is_rob,
-                            robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None)
+                            robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None,
+                            basis=basis)
         ctx.biot_set_alphas(alphas)
         try:
             if alphas:

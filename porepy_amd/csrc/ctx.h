@@ -126,6 +126,8 @@ struct pfv_ctx_impl {
   Buf<uint8_t> bc_dirbits, bc_neubits, bc_robbits;
   Buf<double> mpsa_robw;             // [nd*nd][Nf] Robin weights
   bool have_mpsa_robin = false;
+  Buf<double> mpsa_basis;            // [nd*nd][Nf] boundary basis (BoundaryConditionVectorial.basis)
+  bool have_mpsa_basis = false;
   double mpsa_eta = 0.0;
   Buf<int32_t> cell_nnodes;          // [nc] distinct nodes of a cell (node-volume weights)
   Buf<int64_t> node_eptr, node_ebptr;  // [nn+1] offsets of the per-node expanded rows (cells / boundary faces)

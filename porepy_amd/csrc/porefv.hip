@@ -365,6 +365,7 @@ pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const do
     upload(h->bc_dirbits, bc_dir_bits, (size_t)h->nf, s);
     upload(h->bc_neubits, bc_neu_bits, (size_t)h->nf, s);
     h->have_mpsa_robin = false;
+    h->have_mpsa_basis = false;
     h->mpsa_eta = eta;
     h->have_mpsa_params = true;
     h->have_mpsa_numeric = h->have_mech_system = false;
@@ -388,6 +389,19 @@ pfv_status pfv_mpsa_set_robin(pfv_ctx* h, const uint8_t* bc_rob_bits, const doub
       upload(h->mpsa_robw, eye.data(), n2 * nf, s);
     }
     h->have_mpsa_robin = true;
+    h->have_mpsa_numeric = false;
+    h->have_mech_system = false;
+  });
+}
+
+pfv_status pfv_mpsa_set_basis(pfv_ctx* h, const double* basis_ddn) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_mpsa_params, "pfv_mpsa_set_params first");
+    h->have_mpsa_basis = false;
+    if (basis_ddn) {
+      upload(h->mpsa_basis, basis_ddn, (size_t)h->nd * h->nd * (size_t)h->nf, h->stream);
+      h->have_mpsa_basis = true;
+    }
     h->have_mpsa_numeric = false;
     h->have_mech_system = false;
   });

@@ -4,8 +4,8 @@ Operator API of ``pp.Mpsa`` (numerics/fv/mpsa.py:63-529): ``Mpsa(keyword)``, ``n
 ``discretize(sd, data)``, ``assemble_matrix_rhs(sd, data)``, four ``*_matrix_key`` attributes;
 parameters ``fourth_order_tensor``, ``bc`` (vectorial), ``bc_values`` ((nd, Nf) raveled "F"),
 ``source``, ``mpsa_eta``.  Unknown ordering is cell-major, component-minor (u[nd*c + a]).
-Covered: component-wise Dirichlet / Neumann / Robin conditions in the Cartesian basis.  Rotated
-bases and sub-face conditions raise NotImplementedError.
+Covered: component-wise Dirichlet / Neumann / Robin conditions, also in a face-wise rotated or skewed
+basis (``bc.basis``).  Conditions given per sub-face raise an error.
 """
 from __future__ import annotations
 
@@ -59,10 +59,8 @@ class Mpsa:
             # same failure mode as the reference (mpsa.py:658-659)
             raise AttributeError("MPSA must be given a vectorial boundary condition")
         basis = getattr(bnd, "basis", None)
-        if basis is not None and np.asarray(basis).ndim == 3:
-            eye = np.eye(sd.dim)[:, :, None]
-            if not np.allclose(basis, eye):
-                raise NotImplementedError("rotated boundary bases are not covered yet")
+        if basis is not None and np.asarray(basis).ndim != 3:
+            basis = None
         spec = [pd.get(k) for k in ("specified_cells", "specified_faces", "specified_nodes")]
         partial = any(v is not None for v in spec)
         update = bool(pd.get("update_discretization", False))
@@ -74,7 +72,8 @@ class Mpsa:
         ctx = self.context(sd)
         is_rob = getattr(bnd, "is_rob", None)
         ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta),
-                            is_rob=is_rob, robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None)
+                            is_rob=is_rob, robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None,
+                            basis=basis)
         rows = None
         try:
             if partial:

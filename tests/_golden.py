@@ -44,6 +44,8 @@ class MpsaCase:
         if "bc_is_rob" in z.files:
             self.bc["is_rob"] = z["bc_is_rob"]
             self.bc["robin_weight"] = z["bc_robin_weight"]
+        if "bc_basis" in z.files:
+            self.bc["basis"] = z["bc_basis"]
         self.stiffness = z["stiffness"]
         self.bc_values = z["bc_values"]
         self.source = z["source"]

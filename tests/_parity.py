@@ -348,7 +348,7 @@ def run_mpsa_case(lib, c: MpsaCase):
     ctx.set_grid(c.grid)
     eta = c.eta if c.eta is not None else mo.default_eta(c.grid["name"])
     ctx.mpsa_set_params(c.stiffness, c.grid["cell_volumes"], c.bc["is_dir"], c.bc["is_neu"], eta,
-                        is_rob=c.bc.get("is_rob"), robin_weight=c.bc.get("robin_weight"))
+                        is_rob=c.bc.get("is_rob"), robin_weight=c.bc.get("robin_weight"), basis=c.bc.get("basis"))
     ctx.mpsa_discretize()
     return ctx
 

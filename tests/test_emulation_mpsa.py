@@ -59,12 +59,6 @@ def test_mpsa_rejects_what_it_does_not_cover(lib):
     data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc})
     with pytest.raises(AttributeError):
         pa.Mpsa("mechanics", library=lib).discretize(g, data)
-    bcv = pa.BoundaryConditionVectorial(g)
-    th = 0.3  # rotated boundary basis: not covered, refused
-    bcv.basis = np.tile(np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])[:, :, None], (1, 1, g.num_faces))
-    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bcv})
-    with pytest.raises(NotImplementedError):
-        pa.Mpsa("mechanics", library=lib).discretize(g, data)
 
 
 @pytest.mark.parametrize("name", ["mpsapartial_tri2d_4x4", "mpsapartial_tet3d_2x2x2"])
@@ -83,3 +77,29 @@ def test_amg_block_preconditioner_for_mechanics(lib):
 @pytest.mark.parametrize("name", ["biot_tri2d_3x3_mixed", "biot_cart2d_3x2_dir", "biot_tet_2x2x2_mixed"])
 def test_biot_coupling_terms(lib, name):
     P.check_biot_case(lib, name)
+
+
+def test_rotated_boundary_basis_gives_the_same_solution(lib):
+    """Boundary data given in a face-wise rotated basis, u' = B u: same displacement field as the
+    Cartesian statement of the same problem (tests/numerics/fv/test_mpsa.py:735-860)."""
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTriangleGrid([4, 4], [1, 1])), 0.03)
+    nc, nf = g.num_cells, g.num_faces
+    rng = np.random.default_rng(8)
+    C = pa.FourthOrderTensor(1 + rng.random(nc), 1 + rng.random(nc))
+    bf = g.get_all_boundary_faces()
+    gval = np.zeros((2, nf))
+    gval[:, bf] = rng.random((2, bf.size)) - 0.5
+    sols = []
+    for rotated in (False, True):
+        bc = pa.BoundaryConditionVectorial(g, bf, ["dir"] * bf.size)
+        vals = gval.copy()
+        if rotated:
+            th = rng.random(nf) * 2 * np.pi
+            bc.basis = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+            vals = np.einsum("kcf,cf->kf", bc.basis, gval)
+        data = pa.initialize_data({}, "mech", {"fourth_order_tensor": C, "bc": bc, "bc_values": vals.ravel("F")})
+        d = pa.Mpsa("mech", library=lib)
+        d.discretize(g, data)
+        u, info = d.solve(g, data, rtol=1e-13)
+        sols.append(u)
+    assert np.linalg.norm(sols[0] - sols[1]) <= 1e-9 * np.linalg.norm(sols[0])
