@@ -126,6 +126,14 @@ pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t
                                const double* robin_weight, double eta,
                                const double* eta_subface);
 
+/* Boundary conditions given per SUB-FACE (numerics/fv/mpfa.py:761-768): flags and Robin weights with
+ * one entry per (face, node) pair in face_nodes CSC order (sorted indices), replacing the per-face
+ * arrays of pfv_mpfa_set_params.  The following pfv_mpfa_discretize then keeps sub-face rows (and
+ * sub-face columns of the boundary matrices) in matrices 0-3 -- no collapse to faces, traces not
+ * averaged, Neumann data not divided by the number of face nodes (mpfa.py:1117-1125, 1516-1523) --
+ * while matrices 4-5 keep face rows.  flags = NULL returns to per-face conditions. */
+pfv_status pfv_mpfa_set_subface_bc(pfv_ctx* h, const uint8_t* bc_flags_sub, const double* robin_weight_sub);
+
 /* Mpfa._flux_discretization (numerics/fv/mpfa.py:592-1156) on the device. */
 pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags);
 

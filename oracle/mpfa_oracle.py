@@ -100,11 +100,19 @@ def discretize(
     is_bnd_face = sides_per_face == 1
 
     # Row classes, mpfa.py:1452-1454: internal (fracture) faces are treated as Neumann.
-    is_int = bc.get("is_internal", np.zeros(nf, bool))
-    is_dir = bc["is_dir"] & ~is_int
-    is_rob = bc["is_rob"] & ~is_int
-    is_neu = bc["is_neu"] | is_int
-    rw = np.asarray(bc.get("robin_weight", np.ones(nf)), dtype=float)
+    # Boundary conditions per face, or per sub-face (face_nodes CSC position) when the arrays have one
+    # entry per sub-face (mpfa.py:761-768): then flux / bound_flux / the two trace matrices keep
+    # sub-face rows (no collapse, mpfa.py:1117-1125) and the Neumann data are not divided by the
+    # number of face nodes (mpfa.py:1516-1523)
+    nsub = int(grid["fn_indices"].size)
+    subface_bc = np.asarray(bc["is_dir"]).size == nsub and nsub != nf
+    nbc = nsub if subface_bc else nf
+    is_int = np.asarray(bc.get("is_internal", np.zeros(nbc, bool)), bool)
+    is_dir = np.asarray(bc["is_dir"], bool) & ~is_int
+    is_rob = np.asarray(bc["is_rob"], bool) & ~is_int
+    is_neu = np.asarray(bc["is_neu"], bool) | is_int
+    rw = np.asarray(bc.get("robin_weight", np.ones(nbc)), dtype=float)
+    fn_ptr_, fn_idx_ = grid["fn_indptr"], grid["fn_indices"]
 
     node_start = np.flatnonzero(np.r_[True, h_v[1:] != h_v[:-1], True])
     acc = {k: ([], [], []) for k in MATRIX_KEYS}
@@ -132,16 +140,20 @@ def discretize(
         d_h = xcp - cc[:nd, hc]
         col0 = nd * jloc  # first gradient column of the subcell of each h
 
+        # global sub-face id of every local sub-face, and the index its boundary data live under
+        sfid = np.array([fn_ptr_[f] + int(np.flatnonzero(fn_idx_[fn_ptr_[f]: fn_ptr_[f + 1]] == v)[0]) for f in faces])
+        bid = sfid if subface_bc else faces
+        neu_scale = 1.0 if subface_bc else None
         rows_F, rows_R, rows_P = [], [], []  # local subface index per row, per class
         for s, f in enumerate(faces):
             if not is_bnd_face[f]:
                 rows_F.append(s)
                 rows_P.append(s)
-            elif is_dir[f]:
+            elif is_dir[bid[s]]:
                 rows_P.append(s)
-            elif is_rob[f]:
+            elif is_rob[bid[s]]:
                 rows_R.append(s)
-            elif is_neu[f]:
+            elif is_neu[bid[s]]:
                 rows_F.append(s)
             else:
                 raise ValueError("boundary face without a boundary condition type")
@@ -170,14 +182,14 @@ def discretize(
                 G[r, cols] += sg * nK[:, h]
                 E[r, nd * j : nd * j + nd] += sg * nK[:, h]
                 if is_bnd_face[f]:
-                    Rb[r, bcol[s]] = -1.0 / nn_face[f]
+                    Rb[r, bcol[s]] = -(neu_scale or 1.0 / nn_face[f])
             if ("R", s) in row_of:
                 r = row_of[("R", s)]
                 a_s = farea[f] / nn_face[f]
-                G[r, cols] += sg * nK[:, h] - rw[f] * a_s * d_h[:, h]
-                Rc[r, j] += rw[f] * a_s
+                G[r, cols] += sg * nK[:, h] - rw[bid[s]] * a_s * d_h[:, h]
+                Rc[r, j] += rw[bid[s]] * a_s
                 E[r, nd * j : nd * j + nd] += sg * nK[:, h]
-                Rb[r, bcol[s]] = -1.0 / nn_face[f]
+                Rb[r, bcol[s]] = -(neu_scale or 1.0 / nn_face[f])
             if ("P", s) in row_of:
                 r = row_of[("P", s)]
                 G[r, cols] += sg * d_h[:, h]
@@ -216,26 +228,29 @@ def discretize(
         t_cell, t_bnd, t_vs = Di @ Rc + Dc, Di @ Rb, Di @ E
 
         wf = 1.0 / nn_face[faces]  # subface -> face averaging of traces
-        frow = np.repeat(faces, deg)
+        wrow = np.ones(nsf) if subface_bc else wf
+        rid = sfid if subface_bc else faces
+        frow = np.repeat(rid, deg)
         ccol = np.tile(cells, nsf)
         emit("flux", frow, ccol, q_cell)
-        emit("bound_pressure_cell", frow, ccol, t_cell * wf[:, None])
+        emit("bound_pressure_cell", frow, ccol, t_cell * wrow[:, None])
         if bfaces:
-            bf_ids = faces[bfaces]
-            frow_b = np.repeat(faces, len(bfaces))
+            bf_ids = rid[bfaces]
+            frow_b = np.repeat(rid, len(bfaces))
             bcol_g = np.tile(bf_ids, nsf)
             emit("bound_flux", frow_b, bcol_g, q_bnd)
-            emit("bound_pressure_face", frow_b, bcol_g, t_bnd * wf[:, None])
+            emit("bound_pressure_face", frow_b, bcol_g, t_bnd * wrow[:, None])
         vcol = (cells[:, None] * vd + np.arange(nd)[None, :]).ravel()
         frow_v = np.repeat(faces, deg * nd)
         emit("vector_source", frow_v, np.tile(vcol, nsf), q_vs)
         emit("bound_pressure_vector_source", frow_v, np.tile(vcol, nsf), t_vs * wf[:, None])
 
+    nr = nsub if subface_bc else nf
     shapes = {
-        "flux": (nf, nc),
-        "bound_flux": (nf, nf),
-        "bound_pressure_cell": (nf, nc),
-        "bound_pressure_face": (nf, nf),
+        "flux": (nr, nc),
+        "bound_flux": (nr, nr),
+        "bound_pressure_cell": (nr, nc),
+        "bound_pressure_face": (nr, nr),
         "vector_source": (nf, nc * vd),
         "bound_pressure_vector_source": (nf, nc * vd),
     }

@@ -8,9 +8,9 @@ import numpy as np
 
 def grid_to_raw(g) -> dict:
     """Flatten a reference pp.Grid into the raw-array dict used by oracle and product."""
-    cf = g.cell_faces.tocsc()
+    cf = g.cell_faces.tocsc().copy()  # the reference grid is left as it is
     cf.sort_indices()
-    fn = g.face_nodes.tocsc()
+    fn = g.face_nodes.tocsc().copy()
     fn.sort_indices()
     frac = np.zeros(g.num_faces, dtype=bool)
     for tag in ("fracture_faces",):

@@ -35,7 +35,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
 ]
 
@@ -101,6 +101,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_biot_matrix_info.restype = C.c_int
     lib.pfv_biot_get_matrix.argtypes = [_h, C.c_int, C.c_int, _ip, _ip, _dp]
     lib.pfv_biot_get_matrix.restype = C.c_int
+    lib.pfv_mpfa_set_subface_bc.argtypes = [_h, _up, _dp]
+    lib.pfv_mpfa_set_subface_bc.restype = C.c_int
     lib.pfv_mpsa_set_basis.argtypes = [_h, _dp]
     lib.pfv_mpsa_set_basis.restype = C.c_int
     lib.pfv_mpsa_set_robin.argtypes = [_h, _up, _dp]
@@ -255,6 +257,21 @@ class Context:
             raise ValueError("size of eta must either be 1 or number of subfaces")
         self._check(self.lib.pfv_mpfa_set_params(self._h, _ptr(perm, _dp), _ptr(flags, _up),
                                                  _ptr(rw, _dp), float(eta), _ptr(es, _dp)))
+
+    def set_subface_bc(self, bc_flags_sub, robin_weight_sub=None):
+        """Boundary conditions per sub-face (face_nodes CSC order, sorted indices); None switches back to
+        the per-face conditions of set_params."""
+        if bc_flags_sub is None:
+            self._check(self.lib.pfv_mpfa_set_subface_bc(self._h, None, None))
+            return
+        fl = np.ascontiguousarray(bc_flags_sub, dtype=np.uint8)
+        if fl.shape != (self.nsf,):
+            raise ValueError("one flag per sub-face expected")
+        rw = None if robin_weight_sub is None else _f64(robin_weight_sub)
+        if rw is not None and rw.shape != (self.nsf,):
+            raise ValueError("one Robin weight per sub-face expected")
+        self._check(self.lib.pfv_mpfa_set_subface_bc(self._h, _ptr(fl, _up), _ptr(rw, _dp)))
+        self._discretized = False
 
     # ---- MPSA ----------------------------------------------------------------------
     def mpsa_set_params(self, stiffness, cell_volumes, is_dir, is_neu, eta=0.0, is_rob=None, robin_weight=None,

@@ -146,6 +146,11 @@ struct pfv_ctx_impl {
   CsrPattern pat_user;               // pfv_set_system
   CsrPattern pat_bpf;                // TPFA: bound_pressure_face (diagonal of the Dirichlet / Neumann faces)
   bool rows_complete_m = false;      // every row of the four MPSA matrices holds a discretization
+  bool subface_bc = false;           // conditions per sub-face: matrices 0-3 have sub-face rows
+  Buf<uint8_t> bcflag_s;
+  Buf<double> robin_s;
+  CsrPattern pat_sflux, pat_sbound;
+  bool have_sub_symbolic = false;
   bool tpfa_mode = false;            // matrices 0-5 hold a TPFA discretization
   Buf<double> rhs_u, diag_u;
   std::vector<int32_t> mpsa_class_lds;  // LDS bytes of the largest node per block-size class
@@ -165,11 +170,11 @@ struct pfv_ctx_impl {
     switch (which) {
       case PFV_MAT_FLUX:
       case PFV_MAT_BOUND_PRESSURE_CELL:
-        return pat_flux;
+        return subface_bc ? pat_sflux : pat_flux;
       case PFV_MAT_BOUND_PRESSURE_FACE:
-        return tpfa_mode ? pat_bpf : pat_bound;
+        return subface_bc ? pat_sbound : (tpfa_mode ? pat_bpf : pat_bound);
       case PFV_MAT_BOUND_FLUX:
-        return pat_bound;
+        return subface_bc ? pat_sbound : pat_bound;
       case PFV_MAT_VECTOR_SOURCE:
       case PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE:
         return pat_vs;

@@ -155,6 +155,8 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
     h->rows_complete = false;
     h->rows_complete_m = false;
+    h->have_sub_symbolic = false;
+    h->subface_bc = false;
     h->tpfa_mode = false;
     h->have_mpsa_numeric = h->have_mpsa_symbolic = h->have_mech_system = false;
     h->active.valid = false;
@@ -180,7 +182,27 @@ pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t
     h->have_eta_sub = eta_subface != nullptr;
     if (eta_subface) upload(h->eta_sub, eta_subface, (size_t)h->nsf, s);
     h->have_params = true;
+    h->subface_bc = false;
     h->have_numeric = h->have_system = false;
+  });
+}
+
+pfv_status pfv_mpfa_set_subface_bc(pfv_ctx* h, const uint8_t* bc_flags_sub, const double* robin_weight_sub) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_params, "pfv_mpfa_set_params first");
+    h->subface_bc = false;
+    h->have_numeric = h->have_system = false;
+    h->rows_complete = false;
+    if (!bc_flags_sub) return;
+    const size_t nsf = (size_t)h->nsf;
+    upload(h->bcflag_s, bc_flags_sub, nsf, h->stream);
+    if (robin_weight_sub) {
+      upload(h->robin_s, robin_weight_sub, nsf, h->stream);
+    } else {
+      std::vector<double> ones(nsf, 1.0);
+      upload(h->robin_s, ones.data(), nsf, h->stream);
+    }
+    h->subface_bc = true;
   });
 }
 
@@ -198,16 +220,23 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
       pfv::build_symbolic(*h);
       h->stats.symbolic_ms = tm.stop(s);
       h->tpfa_mode = false;
+      h->have_sub_symbolic = false;
     }
     tm.start(s);
     pfv::run_node_kernel(*h);
     h->stats.node_ms = tm.stop(s);
     const bool with_vs = !(flags & PFV_DISCR_SKIP_VECTOR_SOURCE);
     tm.start(s);
-    pfv::run_face_kernel(*h, with_vs);
+    if (h->subface_bc) {
+      if (!h->have_sub_symbolic || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) pfv::build_subface_symbolic(*h);
+      pfv::run_subface_kernel(*h);
+      if (with_vs) pfv::run_face_kernel(*h, true);
+    } else {
+      pfv::run_face_kernel(*h, with_vs);
+    }
     h->stats.face_ms = tm.stop(s);
     h->have_numeric = true;
-    h->rows_complete = true;
+    h->rows_complete = !h->subface_bc;
     h->have_system = false;
     h->filled[PFV_MAT_SYSTEM] = false;
     double bytes = 0.0;
@@ -242,6 +271,7 @@ pfv_status pfv_mpfa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces
     require(h->have_grid && h->have_params, "grid and parameters must be set before discretize");
     require(n_faces >= 0 && (n_faces == 0 || faces), "bad face list");
     require(h->nd >= 2, "MPFA needs a 2-D or 3-D grid");
+    require(!h->subface_bc, "partial discretization with conditions per sub-face is not covered");
     require(!keep_other_rows || h->rows_complete,
             "update of a discretization that was never computed on this handle");
     for (int64_t i = 0; i < n_faces; ++i)
@@ -323,6 +353,7 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
                              const double* source) {
   return guarded(h, [&] {
     require(h->have_numeric, "discretize first");
+    require(!h->subface_bc, "flux has sub-face rows (conditions per sub-face): collapse it before assembling");
     require(bc_values != nullptr, "bc_values is required");
     require(!vector_source || h->filled[PFV_MAT_VECTOR_SOURCE], "vector_source matrix was skipped");
     auto s = h->stream;

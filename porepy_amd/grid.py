@@ -363,9 +363,9 @@ def perturb_interior_nodes(g: Grid, rate: float, seed: int = 1) -> Grid:
 def grid_to_raw(g) -> dict:
     """Flatten a grid (this package's or the reference's pp.Grid) into the arrays that
     cross the C ABI (include/porefv.h: pfv_set_grid)."""
-    cf = sps.csc_matrix(g.cell_faces)
+    cf = sps.csc_matrix(g.cell_faces, copy=True)  # the caller's arrays are left as they are
     cf.sort_indices()
-    fn = sps.csc_matrix(g.face_nodes)
+    fn = sps.csc_matrix(g.face_nodes, copy=True)
     fn.sort_indices()
     frac = np.zeros(g.num_faces, dtype=bool)
     if "fracture_faces" in getattr(g, "tags", {}):

@@ -40,6 +40,43 @@ def determine_eta(sd) -> float:
     return 1.0 / 3.0 if ("TriangleGrid" in name or "TetrahedralGrid" in name) else 0.0
 
 
+def sps_nnz(m) -> int:
+    return int(m.nnz)
+
+
+def subface_order(face_nodes) -> np.ndarray:
+    """order[p_sorted] = position of the same (face, node) pair in the caller's face_nodes arrays
+    (identity when the indices are already sorted inside every column)."""
+    import scipy.sparse as sps
+
+    fn = sps.csc_matrix(face_nodes)
+    col = np.repeat(np.arange(fn.shape[1]), np.diff(fn.indptr))
+    return np.lexsort((fn.indices, col))
+
+
+def renumber_subfaces(M, order: np.ndarray, cols: bool):
+    """Rows (and columns) from the device's sub-face numbering back to the caller's."""
+    import scipy.sparse as sps
+
+    coo = sps.coo_matrix(M)
+    r = order[coo.row]
+    c = order[coo.col] if cols else coo.col
+    out = sps.csr_matrix((coo.data, (r, c)), shape=M.shape)
+    out.sort_indices()
+    return out
+
+
+class _FaceBC:
+    """All-Neumann per-face placeholder used while the real conditions are given per sub-face."""
+
+    def __init__(self, nf: int):
+        self.is_dir = np.zeros(nf, bool)
+        self.is_neu = np.ones(nf, bool)
+        self.is_rob = np.zeros(nf, bool)
+        self.is_internal = np.zeros(nf, bool)
+        self.robin_weight = np.ones(nf)
+
+
 def plane_basis(nodes: np.ndarray, tol: float = 1e-5):
     """(2, 3) orthonormal basis of the plane holding the nodes of a 2-D grid, or None when the
     grid already lies in a plane z = const (then the first two coordinates are used as is).
@@ -131,8 +168,12 @@ class Mpfa:
         spec = [pd.get(k) for k in ("specified_cells", "specified_faces", "specified_nodes")]
         partial = any(v is not None for v in spec)
         update = bool(pd.get("update_discretization", False))
-        if np.asarray(bnd.is_dir).size != sd.num_faces:
-            raise NotImplementedError("boundary conditions on sub-faces are not covered yet")
+        nsub = sps_nnz(sd.face_nodes)
+        subface = np.asarray(bnd.is_dir).size == nsub and nsub != sd.num_faces
+        if not subface and np.asarray(bnd.is_dir).size != sd.num_faces:
+            raise ValueError("boundary condition arrays must have one entry per face or per sub-face")
+        if subface and (partial or update):
+            raise NotImplementedError("partial discretization with conditions per sub-face is not covered")
         eta = pd.get("mpfa_eta", None)
         eta_sub = None
         if eta is None:
@@ -151,8 +192,18 @@ class Mpfa:
             kval = np.zeros_like(kval)
             kval[:2, :2] = k2
             kval[2, 2] = 1.0
+        order = None
+        if subface:
+            # conditions per sub-face follow the storage order of the caller's face_nodes; the device
+            # numbers sub-faces by the sorted CSC arrays (mpfa.py:761-768, _fvutils.py:78-90)
+            order = subface_order(sd.face_nodes)
+            flags_sub = bc_flags(bnd)[order]
+            robin_sub = np.asarray(bnd.robin_weight, dtype=float)[order]
+            bnd = _FaceBC(sd.num_faces)  # per-face placeholders; the sub-face arrays take over below
         ctx.set_params(kval, bc_flags(bnd), np.asarray(bnd.robin_weight, dtype=float),
                        float(eta), eta_sub)
+        if subface:
+            ctx.set_subface_bc(flags_sub, robin_sub)
         rows = None
         try:
             if partial:
@@ -184,6 +235,8 @@ class Mpfa:
             if lift is not None and "vector_source" in name:
                 new = (new @ lift).tocsr()
                 new.sort_indices()
+            if order is not None and "vector_source" not in name and not np.array_equal(order, np.arange(order.size)):
+                new = renumber_subfaces(new, order, cols=name in ("bound_flux", "bound_pressure_face"))
             if partial and update and rows is not None and name in md:
                 # update without device history: splice the recomputed rows into the caller's
                 # matrices (mpfa.py:466-485)

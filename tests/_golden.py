@@ -20,7 +20,7 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "partial_", "tilted_", "tpfa_", "biot_"))]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "partial_", "tilted_", "tpfa_", "biot_", "subface_"))]
 
 
 def mpsa_case_names():
@@ -234,3 +234,20 @@ class BiotCase:
 
         self.ref = {k: {key: mat(f"ref_{k}__{key}") for key in self.alphas} for k in BIOT_KEYS}
         self.ref_mech = {k: mat("ref_" + k) for k in ("stress", "bound_stress")}
+
+
+class SubfaceCase:
+    """MPFA with boundary conditions per sub-face (oracle/gen_golden_subface.py)."""
+
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.grid["name"] = str(self.grid["name"])
+        self.bc = {k[3:]: z[k] for k in z.files if k.startswith("bc_")}
+        self.perm = z["perm"]
+        self.ref = {}
+        for k in ALL_KEYS:
+            shape = tuple(int(v) for v in z[f"ref_{k}_shape"])
+            self.ref[k] = sps.csr_matrix((z[f"ref_{k}_data"], z[f"ref_{k}_indices"], z[f"ref_{k}_indptr"]), shape=shape)

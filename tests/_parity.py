@@ -7,11 +7,12 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import scipy.sparse.linalg as spla
 
 import porepy_amd as pa
 from oracle import mpfa_oracle as mo
-from tests._golden import BIOT_KEYS, BiotCase, MPSA_KEYS, MpsaPartialCase, ALL_KEYS, Case, PartialCase, TiltedCase, check_pattern, rel_max_err
+from tests._golden import SubfaceCase, BIOT_KEYS, BiotCase, MPSA_KEYS, MpsaPartialCase, ALL_KEYS, Case, PartialCase, TiltedCase, check_pattern, rel_max_err
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMUL_SO = os.path.join(ROOT, "oracle", "_build", "libporefv_emul.so")
@@ -568,3 +569,41 @@ def check_biot_case(lib, name: str):
             assert np.array_equal(M.indptr, ora[k][key].indptr) and np.array_equal(M.indices, ora[k][key].indices), (name, k, key)
             assert rel_max_err(M, ora[k][key]) < TOL, (name, k, key)
             assert rel_max_err(M, c.ref[k][key]) < TOL, (name, k, key)
+
+
+def check_subface_case(lib, name: str, scramble: bool = False):
+    """Boundary conditions per sub-face (mpfa.py:761-768): flux / bound_flux / the trace matrices with
+    sub-face rows against the reference and the oracle.  scramble = True stores face_nodes with the
+    node order inside every column reversed: sub-face data and results then follow that numbering."""
+    import scipy.sparse as sps
+
+    c = SubfaceCase(name)
+    g = pa.grid_from_raw(c.grid)
+    nsub = c.grid["fn_indices"].size
+    perm = np.arange(nsub)
+    if scramble:
+        fn = g.face_nodes.tocsc()
+        ptr = fn.indptr
+        perm = np.concatenate([np.arange(ptr[f], ptr[f + 1])[::-1] for f in range(g.num_faces)])  # user pos -> sorted pos
+        g.face_nodes = sps.csc_matrix((fn.data[perm], fn.indices[perm], ptr.copy()), shape=fn.shape)
+        assert not g.face_nodes.has_sorted_indices or g.dim == 1
+    bc = _RawBC({k: (np.asarray(v)[perm] if np.asarray(v).size == nsub else v) for k, v in c.bc.items()})
+    K = type("K", (), {"values": c.perm})()
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc})
+    d = pa.Mpfa("flow", library=lib)
+    d.discretize(g, data)
+    ora = mo.discretize(c.grid, c.perm, c.bc)
+    inv = np.argsort(perm)  # sorted pos -> user pos
+    for k in ALL_KEYS:
+        M = data[pa.DISCRETIZATION_MATRICES]["flow"][k]
+        ref = c.ref[k]
+        if scramble and "vector_source" not in k:  # bring the reference to the scrambled numbering
+            coo = ref.tocoo()
+            cols = inv[coo.col] if k in ("bound_flux", "bound_pressure_face") else coo.col
+            ref = sps.csr_matrix((coo.data, (inv[coo.row], cols)), shape=ref.shape)
+        assert M.shape == ref.shape, (name, k)
+        assert rel_max_err(M, ref) < TOL, (name, k, scramble)
+        if not scramble:
+            assert rel_max_err(M, ora[k]) < TOL, (name, k)
+    with pytest.raises(pa.PorefvError):  # flux has sub-face rows: no assembly
+        d.assemble_matrix_rhs(g, {**data, pa.PARAMETERS: {"flow": {**data[pa.PARAMETERS]["flow"], "bc_values": np.zeros(g.num_faces)}}})

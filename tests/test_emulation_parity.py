@@ -220,3 +220,9 @@ def test_amg_on_assembled_csr_and_symmetric_cg(lib):
     xa, ia = pa.solve_csr(A, b, method="cg", rtol=1e-12, library=lib, precond="amg")
     assert np.linalg.norm(xa - xo) <= 1e-10 * np.linalg.norm(xo)
     assert ia["iterations"] * 2 < ij["iterations"]
+
+
+@pytest.mark.parametrize("name", ["subface_cart2d_4x3", "subface_tet3d_2x2x2"])
+@pytest.mark.parametrize("scramble", [False, True])
+def test_boundary_conditions_per_subface(lib, name, scramble):
+    P.check_subface_case(lib, name, scramble)

@@ -217,3 +217,9 @@ def test_sharded_driver_single_rank_with_block_amg(lib):
     xa, xj = xa.cpu().numpy(), xj.cpu().numpy()
     assert np.linalg.norm(xa - xj) <= 1e-9 * np.linalg.norm(xj)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("name", ["subface_cart2d_4x3", "subface_tet3d_2x2x2"])
+@pytest.mark.parametrize("scramble", [False, True])
+def test_boundary_conditions_per_subface(lib, name, scramble):
+    P.check_subface_case(lib, name, scramble)
