@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--cpu-n-side", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the secondary lines for BASELINE configs[1] and configs[3] (profiling runs)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (torch-driven sharded solver) on one GPU, for validation")
     args = ap.parse_args()
@@ -377,7 +379,7 @@ def main():
     c2 = c4 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_n_side)
-    if rank == 0 and world == 1 and not args.force_sharded and args.n_side == 69:
+    if rank == 0 and world == 1 and not args.force_sharded and args.n_side == 69 and not args.no_extra_configs:
         try:
             c2 = bench_config_c2(pa, local_rank, args.rtol, args.precond)
         except Exception as e:  # secondary line only
