@@ -277,7 +277,8 @@ pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out);
 /* Measurement hook for bench.py: average duration (ms, HIP events on the handle's stream)
  * of `reps` back-to-back launches of one kernel on the data currently in the handle.
  * kernel: 0 = CSR SpMV with A, 1 = interaction-region (node) kernel, 2 = face kernel. */
-enum { PFV_KERNEL_SPMV_A = 0, PFV_KERNEL_NODE = 1, PFV_KERNEL_FACE = 2 };
+enum { PFV_KERNEL_SPMV_A = 0, PFV_KERNEL_NODE = 1, PFV_KERNEL_FACE = 2,
+       PFV_KERNEL_AMG_SMOOTH = 3 /* finest-level smoothing product of the AMG cycle (needs a built hierarchy) */ };
 pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms);
 
 /* Test hook: copy an internal FP64 device array to the host (0 = rows of A^-1 of all nodes,

@@ -30,6 +30,19 @@ struct CsrPattern {
   int max_row = 0;
 };
 
+// "Windowed" companion of a CSR pattern for the SpMV kernels (spmv_win.inc): per block of 64 rows the
+// sorted list of distinct columns the block touches (its x window, staged in LDS by the kernel) and
+// per entry the 16-bit position of its column in that list.
+struct WinCsr {
+  Buf<int64_t> wptr64buf;
+  const int64_t* wptr64 = nullptr;  // [nblk + 1] offsets into wcol
+  Buf<int32_t> wcol, cnt;
+  Buf<uint16_t> lidx;
+  int64_t nblk = 0, nrows = 0, nnz = 0;
+  int wmax = 0;      // largest window
+  bool ok = false;   // false: not built / some block exceeds the LDS budget -> plain CSR kernels
+};
+
 // a square system the Krylov solver can work on (flow: A = div flux; mechanics: A = div_nd stress)
 struct LinSys {
   const CsrPattern* P = nullptr;
@@ -38,6 +51,7 @@ struct LinSys {
   double* rhs = nullptr;
   int64_t n = 0;
   bool valid = false;
+  const WinCsr* win = nullptr;  // optional (pfv_solve builds it)
 };
 
 struct Amg;  // amg.inc
@@ -156,6 +170,16 @@ struct pfv_ctx_impl {
   std::vector<int32_t> mpsa_class_lds;  // LDS bytes of the largest node per block-size class
   Buf<double> rhs_m, diag_m;
   LinSys active;                     // what pfv_solve / pfv_get_rhs operate on
+  WinCsr win_sys, win_block;         // SpMV windows of the active system / of the leading block (pfv_amg_setup)
+  // The solve runs on a copy of the grid systems renumbered along a space-filling curve of the cell
+  // centres (reorder.inc): the numbering of the grid generator decides how local the SpMV gathers are.
+  bool active_is_grid = false;       // active rows = cells (x active_bs) in the grid's numbering
+  bool have_cell_order = false;
+  Buf<int32_t> cell_perm, cell_iperm;  // new position -> cell, cell -> new position
+  CsrPattern pat_perm;
+  Buf<double> val_perm, diag_perm, rhs_perm, x_perm;
+  const double* perm_for_val = nullptr;  // the values the renumbered copy was made from (nullptr: stale)
+  const int32_t* win_for = nullptr;      // the index array win_sys was built for (nullptr: stale)
   int active_bs = 1;                 // unknowns per cell of the active system (AMG block size)
   int precond = 0;                   // PFV_PRECOND_*
   std::unique_ptr<Amg> amg;          // hierarchy of the active system (rebuilt when the system changes)

@@ -9,6 +9,7 @@
 #include "topology.inc"
 #include "mpfa_numeric.inc"
 #include "linalg.inc"
+#include "reorder.inc"
 #include "mpsa.inc"
 #include "tpfa.inc"
 #include "biot.inc"
@@ -152,6 +153,9 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     upload(h->fn_ptr, fn_indptr, (size_t)nf + 1, s);
     upload(h->fn_idx, fn_indices, (size_t)h->nsf, s);
     h->have_grid = true;
+    h->have_cell_order = false;
+    h->perm_for_val = nullptr;
+    h->win_for = nullptr;
     h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
     h->rows_complete = false;
     h->rows_complete_m = false;
@@ -371,6 +375,8 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     if (!h->have_system) {
       pfv::assemble_system(*h);
       if (h->amg) h->amg->valid = false;
+      h->perm_for_val = nullptr;
+      h->win_for = nullptr;
     }
     pfv::assemble_rhs(*h, d_bc, d_vs, d_src);
     h->stats.assemble_ms = tm.stop(s);
@@ -381,6 +387,7 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     h->active.rhs = h->rhs.p;
     h->active.n = h->nc;
     h->active_bs = 1;
+    h->active_is_grid = true;
     h->active.valid = true;
   });
 }
@@ -628,6 +635,8 @@ pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     if (!h->have_mech_system) {
       pfv::mpsa_assemble_system(*h);
       if (h->amg) h->amg->valid = false;
+      h->perm_for_val = nullptr;
+      h->win_for = nullptr;
     }
     pfv::mpsa_assemble_rhs(*h, in, d_src);
     h->stats.assemble_ms = tm.stop(s);
@@ -638,6 +647,7 @@ pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     h->active.rhs = h->rhs_m.p;
     h->active.n = h->nc * h->nd;
     h->active_bs = h->nd;
+    h->active_is_grid = true;
     h->active.valid = true;
   });
 }
@@ -787,6 +797,9 @@ pfv_status pfv_set_system(pfv_ctx* h, int64_t n, const int32_t* indptr, const in
     h->active.n = n;
     h->active_bs = 1;
     if (h->amg) h->amg->valid = false;
+    h->perm_for_val = nullptr;
+    h->win_for = nullptr;
+    h->active_is_grid = false;
     h->active.valid = true;
   });
 }
@@ -840,7 +853,12 @@ pfv_status pfv_amg_setup(pfv_ctx* h, int64_t n_own) {
       P = &B;
       val = bv;
     }
-    pfv::amg_setup(*h, *h->amg_block, *P, val, bs, h->active.diag);  // the leading block keeps its diagonal
+    const pfv::WinCsr* bw = nullptr;
+    if (P->nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000)) {
+      pfv::win_build(*h, *P, h->win_block);
+      bw = &h->win_block;
+    }
+    pfv::amg_setup(*h, *h->amg_block, *P, val, bs, h->active.diag, bw);  // the leading block keeps its diagonal
     h->stats.amg_setup_ms = h->amg_block->setup_ms;
     h->stats.amg_operator_complexity = h->amg_block->op_complexity;
     h->stats.amg_levels = (int64_t)h->amg_block->nlev;
@@ -863,6 +881,40 @@ pfv_status pfv_set_preconditioner(pfv_ctx* h, int kind) {
   });
 }
 
+// The system the Krylov loop works on: the active one, renumbered along the cell order when it is a
+// grid system (reorder.inc), with the SpMV windows of its pattern (spmv_win.inc).  Copies and
+// windows are kept until the matrix is assembled again.
+static pfv::LinSys solver_system(pfv_ctx* h, bool& permuted) {
+  pfv::LinSys sys = h->active;
+  const int bs = h->active_bs;
+  permuted = false;
+  if (h->active_is_grid && sys.n == h->nc * bs && pfv::env_int("PFV_REORDER", 1) != 0 &&
+      h->nc >= pfv::env_int("PFV_REORDER_MIN_CELLS", 256)) {
+    if (!h->have_cell_order) pfv::build_cell_order(*h);
+    if (h->perm_for_val != sys.val) {
+      pfv::permute_matrix(*h, sys, bs);
+      h->perm_for_val = sys.val;
+      h->win_for = nullptr;
+      if (h->amg) h->amg->valid = false;  // (the copy's buffers are shared by the flow and mechanics systems)
+    }
+    pfv::permute_vector(*h, sys.n, bs, sys.rhs, h->rhs_perm.ensure(sys.n), true);
+    sys.P = &h->pat_perm;
+    sys.val = h->val_perm.p;
+    sys.diag = h->diag_perm.p;
+    sys.rhs = h->rhs_perm.p;
+    permuted = true;
+  }
+  sys.win = nullptr;
+  if (sys.P->nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000)) {
+    if (h->win_for != sys.P->indices.p || !h->win_sys.ok || pfv::env_int("PFV_SPMV_WINDOW", 1) == 0) {
+      pfv::win_build(*h, *sys.P, h->win_sys);
+      h->win_for = sys.P->indices.p;
+    }
+    sys.win = &h->win_sys;
+  }
+  return sys;
+}
+
 pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart, const double* x0,
                      double* x, pfv_solve_info* info) {
   pfv::SolveResult res;
@@ -878,13 +930,21 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
     if (x0) be_h2d(dx, x0, n * sizeof(double), s); else pfv::be_memset(dx, 0, n * sizeof(double), s);
     pfv::Timer tm;
     tm.start(s);
+    bool permuted = false;
+    const pfv::LinSys sys = solver_system(h, permuted);
+    double* dxs = dx;
+    if (permuted) {
+      dxs = h->x_perm.ensure(n);
+      if (x0) pfv::permute_vector(*h, (int64_t)n, h->active_bs, dx, dxs, true);
+      else pfv::be_memset(dxs, 0, n * sizeof(double), s);
+    }
     pfv::Precond M;
     const pfv::Precond* Mp = nullptr;
     if (h->precond == PFV_PRECOND_AMG) {
       if (!h->amg) h->amg = std::make_unique<pfv::Amg>();
-      if (!h->amg->valid || h->amg_for_val != h->active.val) {
-        pfv::amg_setup(*h, *h->amg, *h->active.P, h->active.val, h->active_bs, h->active.diag);
-        h->amg_for_val = h->active.val;
+      if (!h->amg->valid || h->amg_for_val != sys.val) {
+        pfv::amg_setup(*h, *h->amg, *sys.P, sys.val, h->active_bs, sys.diag, sys.win);
+        h->amg_for_val = sys.val;
         h->stats.amg_setup_ms = h->amg->setup_ms;
         h->stats.amg_operator_complexity = h->amg->op_complexity;
         h->stats.amg_levels = (int64_t)h->amg->nlev;
@@ -894,8 +954,9 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
       Mp = &M;
     }
     res = method == PFV_SOLVE_GMRES
-              ? pfv::gmres_solve(*h, h->active, rtol, maxit, restart, dx, x0 == nullptr, Mp)
-              : pfv::krylov_solve(*h, h->active, method, rtol, maxit, dx, x0 == nullptr, Mp);
+              ? pfv::gmres_solve(*h, sys, rtol, maxit, restart, dxs, x0 == nullptr, Mp)
+              : pfv::krylov_solve(*h, sys, method, rtol, maxit, dxs, x0 == nullptr, Mp);
+    if (permuted) pfv::permute_vector(*h, (int64_t)n, h->active_bs, dxs, dx, false);
     h->stats.solve_ms = tm.stop(s);
     be_d2h(x, dx, n * sizeof(double), s);
   });
@@ -930,9 +991,26 @@ pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms) {
       double* x = h->kry[7].ensure(n);
       double* y = h->kry[8].ensure(n);
       pfv::be_d2d(x, h->rhs.p, n * sizeof(double), s);
-      pfv::spmv(*h, h->pat_A, h->val[PFV_MAT_SYSTEM], x, y);
+      // what the Krylov loop launches (renumbered system, windowed kernel when the pattern allows it)
+      require(h->active.valid && h->active.P == &h->pat_A, "the flow system must be the active one");
+      bool permuted = false;
+      const pfv::LinSys sys = solver_system(h, permuted);
+      pfv::sys_spmv(*h, sys, x, y);
       tm.start(s);
-      for (int i = 0; i < reps; ++i) pfv::spmv(*h, h->pat_A, h->val[PFV_MAT_SYSTEM], x, y);
+      for (int i = 0; i < reps; ++i) pfv::sys_spmv(*h, sys, x, y);
+      *avg_ms = tm.stop(s) / reps;
+    } else if (kernel == PFV_KERNEL_AMG_SMOOTH) {
+      require(h->amg && h->amg->valid && h->amg->nlev > 0, "no AMG hierarchy (solve with PFV_PRECOND_AMG first)");
+      pfv::AmgLevel& L = *h->amg->lev[0];
+      const size_t n = (size_t)L.n;
+      double* x = h->kry[7].ensure(n);
+      double* y = h->kry[8].ensure(n);
+      double* b = h->kry[6].ensure(n);
+      pfv::be_memset(x, 0, n * sizeof(double), s);
+      pfv::be_memset(b, 0, n * sizeof(double), s);
+      pfv::amg_spmv(*h, *h->amg, L, x, y, b);
+      tm.start(s);
+      for (int i = 0; i < reps; ++i) pfv::amg_spmv(*h, *h->amg, L, x, y, b);
       *avg_ms = tm.stop(s) / reps;
     } else if (kernel == PFV_KERNEL_NODE) {
       require(h->have_numeric, "discretize first");

@@ -190,6 +190,39 @@ def test_amg_preconditioner(lib):
     P.amg_preconditioner(lib, g)
 
 
+def test_windowed_spmv_paths(lib, monkeypatch):
+    """The solve's SpMV stages per-block x windows in LDS (spmv_win.inc).  Unsorted rows through the
+    windowed kernels; a matrix without locality (a block touches > 4096 columns) falls back to the
+    plain CSR kernels; windowed and plain give the same solution of a grid system."""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+
+    rng = np.random.default_rng(11)
+    monkeypatch.setenv("PFV_SPMV_WINDOW_MIN_NNZ", "0")
+    n = 700
+    A = sps.csr_matrix(sps.random(n, n, density=0.03, random_state=2, format="csr") + sps.diags(30 + rng.random(n)))
+    perm = np.concatenate([rng.permutation(np.arange(A.indptr[i], A.indptr[i + 1])) for i in range(n)])
+    A = sps.csr_matrix((A.data[perm], A.indices[perm], A.indptr), shape=A.shape)
+    b = rng.random(n)
+    xo = spla.spsolve(A.tocsc(), b)
+    for method, precond in (("bicgstab", "jacobi"), ("gmres", "jacobi"), ("bicgstab", "amg")):
+        x, info = pa.solve_csr(A, b, method=method, rtol=1e-13, precond=precond, library=lib)
+        assert np.linalg.norm(x - xo) <= 1e-10 * np.linalg.norm(xo), (method, precond)
+    n = 6000  # 64 rows x 80 random columns: no window fits
+    A = sps.csr_matrix(sps.random(n, n, density=80 / n, random_state=3, format="csr") + sps.diags(200 + rng.random(n)))
+    b = rng.random(n)
+    x, info = pa.solve_csr(A, b, method="bicgstab", rtol=1e-13, library=lib)
+    assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(b)
+    monkeypatch.delenv("PFV_SPMV_WINDOW_MIN_NNZ")
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([9, 9, 9], [1, 1, 1])), 0.02)
+    sols = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PFV_SPMV_WINDOW", flag)
+        out, _, _ = P.amg_preconditioner(lib, g)
+        sols.append(out)
+    assert abs(sols[0]["bicgstab"] - sols[1]["bicgstab"]) <= 2, sols
+
+
 def test_sharded_driver_single_rank_with_block_amg(lib):
     """The multi-GPU driver on one rank (no exchange): device-pointer SpMV, block-AMG V-cycles on torch
     tensors, against the single-context solve."""
