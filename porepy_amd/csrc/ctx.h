@@ -170,6 +170,9 @@ struct pfv_ctx_impl {
   std::vector<int32_t> mpsa_class_lds;  // LDS bytes of the largest node per block-size class
   Buf<double> rhs_m, diag_m;
   LinSys active;                     // what pfv_solve / pfv_get_rhs operate on
+  WinCsr win_rows;                   // window of the leading rows of a system matrix (pfv_spmv_device_rows)
+  const int32_t* win_rows_for = nullptr;
+  int64_t win_rows_n = 0;
   WinCsr win_sys, win_block;         // SpMV windows of the active system / of the leading block (pfv_amg_setup)
   // The solve runs on a copy of the grid systems renumbered along a space-filling curve of the cell
   // centres (reorder.inc): the numbering of the grid generator decides how local the SpMV gathers are.

@@ -155,7 +155,7 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     h->have_grid = true;
     h->have_cell_order = false;
     h->perm_for_val = nullptr;
-    h->win_for = nullptr;
+    h->win_for = h->win_rows_for = nullptr;
     h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
     h->rows_complete = false;
     h->rows_complete_m = false;
@@ -376,7 +376,7 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
       pfv::assemble_system(*h);
       if (h->amg) h->amg->valid = false;
       h->perm_for_val = nullptr;
-      h->win_for = nullptr;
+      h->win_for = h->win_rows_for = nullptr;
     }
     pfv::assemble_rhs(*h, d_bc, d_vs, d_src);
     h->stats.assemble_ms = tm.stop(s);
@@ -636,7 +636,7 @@ pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* 
       pfv::mpsa_assemble_system(*h);
       if (h->amg) h->amg->valid = false;
       h->perm_for_val = nullptr;
-      h->win_for = nullptr;
+      h->win_for = h->win_rows_for = nullptr;
     }
     pfv::mpsa_assemble_rhs(*h, in, d_src);
     h->stats.assemble_ms = tm.stop(s);
@@ -695,7 +695,27 @@ pfv_status pfv_spmv_device_rows(pfv_ctx* h, int which, int64_t nrows, const doub
     V.indptr.p = P.indptr.p;
     V.indices.p = P.indices.p;
     try {
-      pfv::spmv(*h, V, h->val[which], d_x, d_y);
+      const bool sysmat = which == PFV_MAT_SYSTEM || which == PFV_MAT_MECH_SYSTEM || which == PFV_MAT_USER_SYSTEM;
+      bool done = false;
+      if (sysmat && nrows > 0 && P.nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000)) {
+        // the sharded Krylov loop's product with the owned rows: windowed kernel, window kept until
+        // the matrix is assembled again
+        if (h->win_rows_for != P.indices.p || h->win_rows_n != nrows) {
+          V.nnz = P.nnz;  // (lidx is indexed by entry position)
+          pfv::win_build(*h, V, h->win_rows);
+          h->win_rows_for = P.indices.p;
+          h->win_rows_n = nrows;
+        }
+        if (h->win_rows.ok) {
+          pfv::LinSys sys;
+          sys.P = &V;
+          sys.val = h->val[which].p;
+          sys.win = &h->win_rows;
+          pfv::sys_spmv(*h, sys, d_x, d_y);
+          done = true;
+        }
+      }
+      if (!done) pfv::spmv(*h, V, h->val[which], d_x, d_y);
     } catch (...) {
       V.indptr.p = nullptr;
       V.indices.p = nullptr;
@@ -798,7 +818,7 @@ pfv_status pfv_set_system(pfv_ctx* h, int64_t n, const int32_t* indptr, const in
     h->active_bs = 1;
     if (h->amg) h->amg->valid = false;
     h->perm_for_val = nullptr;
-    h->win_for = nullptr;
+    h->win_for = h->win_rows_for = nullptr;
     h->active_is_grid = false;
     h->active.valid = true;
   });
@@ -894,7 +914,7 @@ static pfv::LinSys solver_system(pfv_ctx* h, bool& permuted) {
     if (h->perm_for_val != sys.val) {
       pfv::permute_matrix(*h, sys, bs);
       h->perm_for_val = sys.val;
-      h->win_for = nullptr;
+      h->win_for = h->win_rows_for = nullptr;
       if (h->amg) h->amg->valid = false;  // (the copy's buffers are shared by the flow and mechanics systems)
     }
     pfv::permute_vector(*h, sys.n, bs, sys.rhs, h->rhs_perm.ensure(sys.n), true);
@@ -1000,17 +1020,18 @@ pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms) {
       for (int i = 0; i < reps; ++i) pfv::sys_spmv(*h, sys, x, y);
       *avg_ms = tm.stop(s) / reps;
     } else if (kernel == PFV_KERNEL_AMG_SMOOTH) {
-      require(h->amg && h->amg->valid && h->amg->nlev > 0, "no AMG hierarchy (solve with PFV_PRECOND_AMG first)");
-      pfv::AmgLevel& L = *h->amg->lev[0];
+      pfv::Amg* amg = (h->amg && h->amg->valid) ? h->amg.get() : h->amg_block.get();  // single-GPU / sharded
+      require(amg && amg->valid && amg->nlev > 0, "no AMG hierarchy (solve with PFV_PRECOND_AMG first)");
+      pfv::AmgLevel& L = *amg->lev[0];
       const size_t n = (size_t)L.n;
       double* x = h->kry[7].ensure(n);
       double* y = h->kry[8].ensure(n);
       double* b = h->kry[6].ensure(n);
       pfv::be_memset(x, 0, n * sizeof(double), s);
       pfv::be_memset(b, 0, n * sizeof(double), s);
-      pfv::amg_spmv(*h, *h->amg, L, x, y, b);
+      pfv::amg_spmv(*h, *amg, L, x, y, b);
       tm.start(s);
-      for (int i = 0; i < reps; ++i) pfv::amg_spmv(*h, *h->amg, L, x, y, b);
+      for (int i = 0; i < reps; ++i) pfv::amg_spmv(*h, *amg, L, x, y, b);
       *avg_ms = tm.stop(s) / reps;
     } else if (kernel == PFV_KERNEL_NODE) {
       require(h->have_numeric, "discretize first");
