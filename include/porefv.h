@@ -202,6 +202,13 @@ pfv_status pfv_biot_get_matrix(pfv_ctx* h, int term, int key, int32_t* indptr, i
 pfv_status pfv_set_system(pfv_ctx* h, int64_t n, const int32_t* indptr, const int32_t* indices,
                           const double* data, const double* rhs);
 
+/* Where the vector arguments of pfv_mpfa_assemble (bc_values, vector_source, source),
+ * pfv_mpsa_assemble (bc_values, source) and pfv_solve (x0, x) live: 0 (default) host memory, as the
+ * reference's numpy arrays (fv_elliptic.py:67-112); 1 device memory of this handle's GPU - models
+ * that keep iterating on the device skip PCIe altogether.  Device buffers must be complete on the
+ * handle's stream (see pfv_set_stream) when the call is made; pfv_solve returns after x is written. */
+pfv_status pfv_set_vectors_on_device(pfv_ctx* h, int on);
+
 /* Select the preconditioner of the following pfv_solve calls on this handle. */
 pfv_status pfv_set_preconditioner(pfv_ctx* h, int kind);
 

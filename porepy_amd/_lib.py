@@ -37,6 +37,7 @@ EXPORTS = [
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
     "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
+    "pfv_set_vectors_on_device",
 ]
 
 
@@ -113,6 +114,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_amg_setup.restype = C.c_int
     lib.pfv_amg_apply_device.argtypes = [_h, C.c_void_p, C.c_void_p]
     lib.pfv_amg_apply_device.restype = C.c_int
+    lib.pfv_set_vectors_on_device.argtypes = [_h, C.c_int]
+    lib.pfv_set_vectors_on_device.restype = C.c_int
     lib.pfv_set_preconditioner.argtypes = [_h, C.c_int]
     lib.pfv_set_preconditioner.restype = C.c_int
     lib.pfv_tpfa_discretize.argtypes = [_h, C.c_int]
@@ -416,6 +419,44 @@ class Context:
         if src is not None and src.shape != (self.nc,):
             raise ValueError("source must have one entry per cell")
         self._check(self.lib.pfv_mpfa_assemble(self._h, _ptr(bcv, _dp), _ptr(vs, _dp), _ptr(src, _dp)))
+
+    # ---- device-resident vectors (addresses of device buffers, e.g. torch.Tensor.data_ptr()) ----
+    def _dev(self, on: bool):
+        self._check(self.lib.pfv_set_vectors_on_device(self._h, 1 if on else 0))
+
+    def assemble_device(self, bc_ptr: int, vs_ptr: int = 0, src_ptr: int = 0):
+        """``assemble`` with device buffers: Nf bc values, optional vector source, optional Nc sources."""
+        self._dev(True)
+        try:
+            self._check(self.lib.pfv_mpfa_assemble(self._h, C.cast(bc_ptr, _dp), C.cast(vs_ptr or None, _dp),
+                                                   C.cast(src_ptr or None, _dp)))
+        finally:
+            self._dev(False)
+
+    def mpsa_assemble_device(self, bc_ptr: int, src_ptr: int = 0):
+        self._dev(True)
+        try:
+            self._check(self.lib.pfv_mpsa_assemble(self._h, C.cast(bc_ptr, _dp), C.cast(src_ptr or None, _dp)))
+        finally:
+            self._dev(False)
+
+    def solve_device(self, x_ptr: int, method="bicgstab", rtol=1e-12, maxit=10000, x0_ptr: int = 0,
+                     raise_on_fail=True, restart=0, precond="jacobi"):
+        """``solve`` writing the solution into the device buffer at ``x_ptr`` (n doubles); returns info."""
+        code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB, "gmres": SOLVE_GMRES}[method]
+        self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1}[precond]))
+        info = SolveInfo()
+        self._dev(True)
+        try:
+            st = self.lib.pfv_solve(self._h, code, float(rtol), int(maxit), int(restart), C.cast(x0_ptr or None, _dp),
+                                    C.cast(x_ptr, _dp), C.byref(info))
+        finally:
+            self._dev(False)
+        out = {"iterations": info.iterations, "converged": bool(info.converged),
+               "rel_residual": info.rel_residual, "solve_ms": info.solve_ms}
+        if st != 0 and (raise_on_fail or st != 6):
+            self._check(st)
+        return out
 
     def rhs(self):
         b = np.empty(self.nc, dtype=np.float64)

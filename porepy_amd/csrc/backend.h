@@ -23,6 +23,7 @@
 #include <numeric>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #ifdef PFV_EMULATE
@@ -63,8 +64,7 @@ using stream_t = int;
 #endif
 
 // ---------------------------------------------------------------- memory
-inline void* be_malloc(size_t bytes) {
-  if (bytes == 0) bytes = 8;
+inline void* raw_malloc(size_t bytes) {
 #ifdef PFV_EMULATE
   void* p = std::malloc(bytes);
   if (!p) throw Error(3, "host emulation: out of memory");
@@ -75,13 +75,76 @@ inline void* be_malloc(size_t bytes) {
   return p;
 #endif
 }
-inline void be_free(void* p) {
-  if (!p) return;
+inline void raw_free(void* p) {
 #ifdef PFV_EMULATE
   std::free(p);
 #else
   (void)hipFree(p);
 #endif
+}
+
+// Per-handle cache of device blocks.  The setup phases allocate a few dozen temporaries per call;
+// hipMalloc / hipFree cost tens of microseconds each on a good day and hipFree synchronises the
+// device (on a loaded host the symbolic phase went from 16 to 37 ms that way).  Freed blocks are
+// kept and handed out again to requests of a similar size.  All work of a handle is ordered on its
+// one stream (pfv_set_stream synchronises before switching), so a block that is reused while
+// kernels that read its previous contents are still queued is safe.
+struct MemPool {
+  struct Blk { void* p; size_t bytes; };
+  std::vector<Blk> free_list;
+  std::unordered_map<void*, size_t> live;
+  size_t cached = 0;
+  static constexpr size_t kMaxCached = size_t(48) << 30;
+  void* take(size_t bytes) {
+    size_t best = (size_t)-1, best_bytes = (size_t)-1;
+    for (size_t i = 0; i < free_list.size(); ++i) {
+      const size_t b = free_list[i].bytes;
+      if (b >= bytes && b <= 2 * bytes + (size_t(1) << 16) && b < best_bytes) { best = i; best_bytes = b; }
+    }
+    void* p;
+    if (best != (size_t)-1) {
+      p = free_list[best].p;
+      cached -= best_bytes;
+      free_list[best] = free_list.back();
+      free_list.pop_back();
+      live[p] = best_bytes;
+    } else {
+      p = raw_malloc(bytes);
+      live[p] = bytes;
+    }
+    return p;
+  }
+  bool give(void* p) {  // false: not one of ours
+    auto it = live.find(p);
+    if (it == live.end()) return false;
+    const size_t b = it->second;
+    live.erase(it);
+    if (cached + b > kMaxCached) raw_free(p);
+    else { free_list.push_back({p, b}); cached += b; }
+    return true;
+  }
+  void trim() {
+    for (auto& b : free_list) raw_free(b.p);
+    free_list.clear();
+    cached = 0;
+  }
+  ~MemPool() { trim(); }
+};
+inline thread_local MemPool* tls_pool = nullptr;  // set for the duration of an API call (porefv.hip: guarded)
+struct PoolScope {
+  MemPool* prev;
+  explicit PoolScope(MemPool* p) : prev(tls_pool) { tls_pool = p; }
+  ~PoolScope() { tls_pool = prev; }
+};
+
+inline void* be_malloc(size_t bytes) {
+  if (bytes == 0) bytes = 8;
+  return tls_pool ? tls_pool->take(bytes) : raw_malloc(bytes);
+}
+inline void be_free(void* p) {
+  if (!p) return;
+  if (tls_pool && tls_pool->give(p)) return;
+  raw_free(p);
 }
 inline void be_h2d(void* dst, const void* src, size_t bytes, stream_t s) {
   if (!bytes) return;

@@ -57,6 +57,7 @@ struct LinSys {
 struct Amg;  // amg.inc
 
 struct pfv_ctx_impl {
+  MemPool pool;     // first member: destroyed last, after every buffer has been handed back
   pfv_ctx_impl();
   ~pfv_ctx_impl();  // defined where Amg is complete (porefv.hip)
   int device = 0;
@@ -169,6 +170,7 @@ struct pfv_ctx_impl {
   Buf<double> rhs_u, diag_u;
   std::vector<int32_t> mpsa_class_lds;  // LDS bytes of the largest node per block-size class
   Buf<double> rhs_m, diag_m;
+  bool vectors_on_device = false;    // pfv_set_vectors_on_device
   LinSys active;                     // what pfv_solve / pfv_get_rhs operate on
   WinCsr win_rows;                   // window of the leading rows of a system matrix (pfv_spmv_device_rows)
   const int32_t* win_rows_for = nullptr;

@@ -28,6 +28,7 @@ namespace {
 template <class F>
 pfv_status guarded(pfv_ctx* h, F&& body) {
   if (!h) return PFV_ERR_ARGUMENT;
+  pfv::PoolScope pool_scope(&h->pool);
   try {
 #ifndef PFV_EMULATE
     PFV_HIP_CHECK(hipSetDevice(h->device));
@@ -103,14 +104,31 @@ void pfv_destroy(pfv_ctx* h) {
     (void)hipStreamSynchronize(h->stream);
   }
   hipStream_t s = h->own_stream;
-  delete h;
+  {
+    pfv::PoolScope pool_scope(&h->pool);
+    delete h;
+  }
   if (s) (void)hipStreamDestroy(s);
 #else
-  delete h;
+  {
+    pfv::PoolScope pool_scope(&h->pool);
+    delete h;
+  }
 #endif
 }
 
 const char* pfv_last_error(pfv_ctx* h) { return h ? h->err.c_str() : "null handle"; }
+
+// right-hand-side / solution vectors of the assemble and solve calls: host memory by default, device
+// memory after pfv_set_vectors_on_device(h, 1)
+static void vec_in(pfv_ctx* h, double* dst, const double* src, size_t n) {
+  if (h->vectors_on_device) pfv::be_d2d(dst, src, n * sizeof(double), h->stream);
+  else be_h2d(dst, src, n * sizeof(double), h->stream);
+}
+
+pfv_status pfv_set_vectors_on_device(pfv_ctx* h, int on) {
+  return guarded(h, [&] { h->vectors_on_device = on != 0; });
+}
 
 pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, const double* nodes,
                         const int32_t* cf_indptr, const int32_t* cf_indices, const int8_t* cf_sign,
@@ -125,6 +143,8 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
             "null grid array");
     require(nc < (int64_t(1) << 31) && nf < (int64_t(1) << 31) && nn < (int64_t(1) << 31), "grid too large for int32 ids");
     auto s = h->stream;
+    pfv::be_sync(s);
+    h->pool.trim();  // a new grid: the cached block sizes are of no use any more
     h->nd = nd;
     h->nc = nc;
     h->nf = nf;
@@ -368,9 +388,9 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     double* d_bc = in;
     double* d_vs = vector_source ? in + nf : nullptr;
     double* d_src = source ? in + nf + nvs : nullptr;
-    be_h2d(d_bc, bc_values, nf * sizeof(double), s);
-    if (d_vs) be_h2d(d_vs, vector_source, nvs * sizeof(double), s);
-    if (d_src) be_h2d(d_src, source, nc * sizeof(double), s);
+    vec_in(h, d_bc, bc_values, nf);
+    if (d_vs) vec_in(h, d_vs, vector_source, nvs);
+    if (d_src) vec_in(h, d_src, source, nc);
     tm.start(s);
     if (!h->have_system) {
       pfv::assemble_system(*h);
@@ -624,11 +644,11 @@ pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     auto s = h->stream;
     const size_t nfd = (size_t)h->nf * h->nd, ncd = (size_t)h->nc * h->nd;
     double* in = h->vec_in.ensure(nfd + ncd);
-    be_h2d(in, bc_values, nfd * sizeof(double), s);
+    vec_in(h, in, bc_values, nfd);
     double* d_src = nullptr;
     if (source) {
       d_src = in + nfd;
-      be_h2d(d_src, source, ncd * sizeof(double), s);
+      vec_in(h, d_src, source, ncd);
     }
     pfv::Timer tm;
     tm.start(s);
@@ -947,7 +967,7 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
     auto s = h->stream;
     const size_t n = (size_t)h->active.n;
     double* dx = h->xsol.ensure(n);
-    if (x0) be_h2d(dx, x0, n * sizeof(double), s); else pfv::be_memset(dx, 0, n * sizeof(double), s);
+    if (x0) vec_in(h, dx, x0, n); else pfv::be_memset(dx, 0, n * sizeof(double), s);
     pfv::Timer tm;
     tm.start(s);
     bool permuted = false;
@@ -978,7 +998,7 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
               : pfv::krylov_solve(*h, sys, method, rtol, maxit, dxs, x0 == nullptr, Mp);
     if (permuted) pfv::permute_vector(*h, (int64_t)n, h->active_bs, dxs, dx, false);
     h->stats.solve_ms = tm.stop(s);
-    be_d2h(x, dx, n * sizeof(double), s);
+    if (h->vectors_on_device) pfv::be_d2d(x, dx, n * sizeof(double), s); else be_d2h(x, dx, n * sizeof(double), s);
   });
   if (info) {
     info->iterations = res.iterations;

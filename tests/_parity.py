@@ -607,3 +607,40 @@ def check_subface_case(lib, name: str, scramble: bool = False):
             assert rel_max_err(M, ora[k]) < TOL, (name, k)
     with pytest.raises(pa.PorefvError):  # flux has sub-face rows: no assembly
         d.assemble_matrix_rhs(g, {**data, pa.PARAMETERS: {"flow": {**data[pa.PARAMETERS]["flow"], "bc_values": np.zeros(g.num_faces)}}})
+
+
+def device_resident_vectors(lib, g, to_device=None, from_device=None):
+    """pfv_set_vectors_on_device: bc values / source / solution exchanged as device buffers give the
+    same system and solution as the host-array calls.  ``to_device(array) -> (address, keepalive)``;
+    the host emulation passes numpy addresses."""
+    rng = np.random.default_rng(4)
+    nc, nf = g.num_cells, g.num_faces
+    K = pa.SecondOrderTensor(kxx=1 + rng.random(nc), kyy=2 + rng.random(nc), kzz=(0.5 + rng.random(nc)) if g.dim == 3 else None)
+    bf = g.get_all_boundary_faces()
+    bc = pa.BoundaryCondition(g, bf, ["dir"] * bf.size)
+    bv = np.zeros(nf)
+    bv[bf] = rng.random(bf.size)
+    src = rng.random(nc) * g.cell_volumes
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(pa.grid_to_raw(g))
+    ctx.set_params(K.values, pa.bc_flags(bc), bc.robin_weight, pa.determine_eta(g))
+    ctx.discretize()
+    ctx.assemble(bv, None, src)
+    b_host = ctx.rhs()
+    x_host, info_h = ctx.solve("bicgstab", rtol=1e-12, precond="amg")
+    if to_device is None:
+        to_device = lambda a: (a.ctypes.data, a)  # noqa: E731
+        from_device = lambda keep: keep  # noqa: E731
+    p_bv, k1 = to_device(np.ascontiguousarray(bv))
+    p_src, k2 = to_device(np.ascontiguousarray(src))
+    p_x, k3 = to_device(np.zeros(nc))
+    ctx.assemble_device(p_bv, 0, p_src)
+    assert np.array_equal(ctx.rhs(), b_host)
+    info_d = ctx.solve_device(p_x, "bicgstab", rtol=1e-12, precond="amg")
+    ctx.sync()
+    x_dev = np.asarray(from_device(k3))
+    assert info_d["iterations"] == info_h["iterations"]
+    assert np.array_equal(x_dev, x_host)
+    # and the host calls still work afterwards
+    x2, _ = ctx.solve("bicgstab", rtol=1e-12, precond="amg")
+    assert np.array_equal(x2, x_host)

@@ -226,3 +226,8 @@ def test_amg_on_assembled_csr_and_symmetric_cg(lib):
 @pytest.mark.parametrize("scramble", [False, True])
 def test_boundary_conditions_per_subface(lib, name, scramble):
     P.check_subface_case(lib, name, scramble)
+
+
+def test_device_resident_vectors(lib):
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([4, 4, 4], [1, 1, 1])), 0.03)
+    P.device_resident_vectors(lib, g)

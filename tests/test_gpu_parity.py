@@ -256,3 +256,15 @@ def test_sharded_driver_single_rank_with_block_amg(lib):
 @pytest.mark.parametrize("scramble", [False, True])
 def test_boundary_conditions_per_subface(lib, name, scramble):
     P.check_subface_case(lib, name, scramble)
+
+
+def test_device_resident_vectors(lib):
+    import torch
+
+    def to_device(a):
+        t = torch.from_numpy(a).cuda()
+        torch.cuda.synchronize()
+        return t.data_ptr(), t
+
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([6, 6, 6], [1, 1, 1])), 0.03)
+    P.device_resident_vectors(lib, g, to_device, lambda t: t.cpu().numpy())
