@@ -202,6 +202,16 @@ pfv_status pfv_biot_get_matrix(pfv_ctx* h, int term, int key, int32_t* indptr, i
 pfv_status pfv_set_system(pfv_ctx* h, int64_t n, const int32_t* indptr, const int32_t* indices,
                           const double* data, const double* rhs);
 
+/* Periodic faces (Grid.set_periodic_map, grids/grid.py:879-911; SubcellTopology merges the right
+ * sub-faces and nodes into the left ones, numerics/fv/_fvutils.py:91-137; Tpfa pairs the cells,
+ * numerics/fv/tpfa.py:114-262).  The host passes the *merged* grid to pfv_set_grid (the right cell lists
+ * the left face, right nodes renamed to left nodes, right faces left without cells and nodes;
+ * porepy_amd/periodic.py) and tells here which side of a merged face is displaced: for every face f,
+ * native_cell[f] = the cell that sees the face where it is (-1: not a periodic face) and
+ * shift[3][Nf] (SoA) = x_f(left) - x_f(right); every other cell of f sees the face centre at
+ * face_centers[f] - shift[f].  Call after pfv_set_grid (which clears it); NULL, NULL clears. */
+pfv_status pfv_set_periodic(pfv_ctx* h, const int32_t* native_cell, const double* shift);
+
 /* Where the vector arguments of pfv_mpfa_assemble (bc_values, vector_source, source),
  * pfv_mpsa_assemble (bc_values, source) and pfv_solve (x0, x) live: 0 (default) host memory, as the
  * reference's numpy arrays (fv_elliptic.py:67-112); 1 device memory of this handle's GPU - models

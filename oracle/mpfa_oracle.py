@@ -136,7 +136,14 @@ def discretize(
         n_h = fnrm[:nd, hf] / nn_face[hf]  # (nd, nh), stored orientation
         nK = np.einsum("ih,ijh->jh", n_h, perm[:nd, :nd, hc])  # n^T K -> (nd, nh)
         eta_h = np.where(is_bnd_face[hf], 0.0, eta)
-        xcp = fc[:nd, hf] + eta_h * (nodes[:nd, [v]] - fc[:nd, hf])
+        fch = fc[:nd, hf]
+        if "periodic_native" in grid:
+            # merged periodic faces (porepy_amd/periodic.py; reference _fvutils.py:91-137): the side
+            # that is not the face's own cell sees the face centre displaced by the period
+            nat = np.asarray(grid["periodic_native"])[hf]
+            far = (nat >= 0) & (nat != hc)
+            fch = fch - np.asarray(grid["periodic_shift"])[:nd, hf] * far
+        xcp = fch + eta_h * (nodes[:nd, [v]] - fch)
         d_h = xcp - cc[:nd, hc]
         col0 = nd * jloc  # first gradient column of the subcell of each h
 

@@ -37,7 +37,7 @@ EXPORTS = [
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
     "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
-    "pfv_set_vectors_on_device",
+    "pfv_set_vectors_on_device", "pfv_set_periodic",
 ]
 
 
@@ -114,6 +114,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_amg_setup.restype = C.c_int
     lib.pfv_amg_apply_device.argtypes = [_h, C.c_void_p, C.c_void_p]
     lib.pfv_amg_apply_device.restype = C.c_int
+    lib.pfv_set_periodic.argtypes = [_h, C.POINTER(C.c_int32), _dp]
+    lib.pfv_set_periodic.restype = C.c_int
     lib.pfv_set_vectors_on_device.argtypes = [_h, C.c_int]
     lib.pfv_set_vectors_on_device.restype = C.c_int
     lib.pfv_set_preconditioner.argtypes = [_h, C.c_int]
@@ -419,6 +421,14 @@ class Context:
         if src is not None and src.shape != (self.nc,):
             raise ValueError("source must have one entry per cell")
         self._check(self.lib.pfv_mpfa_assemble(self._h, _ptr(bcv, _dp), _ptr(vs, _dp), _ptr(src, _dp)))
+
+    def set_periodic(self, native_cell, shift):
+        """Displaced sides of merged periodic faces (include/porefv.h: pfv_set_periodic)."""
+        nat = np.ascontiguousarray(native_cell, dtype=np.int32)
+        sh = np.ascontiguousarray(shift, dtype=np.float64)
+        if nat.shape != (self.nf,) or sh.shape != (3, self.nf):
+            raise ValueError("native_cell must be (Nf,), shift (3, Nf)")
+        self._check(self.lib.pfv_set_periodic(self._h, nat.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(sh, _dp)))
 
     # ---- device-resident vectors (addresses of device buffers, e.g. torch.Tensor.data_ptr()) ----
     def _dev(self, on: bool):

@@ -71,6 +71,11 @@ struct pfv_ctx_impl {
   int nd = 0;
   int64_t nc = 0, nf = 0, nn = 0, ncf = 0, nsf = 0;  // ncf = nnz(cell_faces), nsf = nnz(face_nodes)
   Buf<double> nodes, fnorm, fcen, ccen, farea;
+  // periodic faces (pfv_set_periodic): the side of face f that is not its native cell sees the face
+  // centre fcen[f] - face_shift[f]
+  bool periodic = false;
+  Buf<double> face_shift;    // SoA [3][Nf]
+  Buf<int32_t> face_native;  // [Nf] cell, or -1
   Buf<int32_t> cf_ptr, cf_idx, fn_ptr, fn_idx;
   Buf<int8_t> cf_sgn;
 

@@ -173,6 +173,7 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     upload(h->fn_ptr, fn_indptr, (size_t)nf + 1, s);
     upload(h->fn_idx, fn_indices, (size_t)h->nsf, s);
     h->have_grid = true;
+    h->periodic = false;
     h->have_cell_order = false;
     h->perm_for_val = nullptr;
     h->win_for = h->win_rows_for = nullptr;
@@ -185,6 +186,22 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     h->have_mpsa_numeric = h->have_mpsa_symbolic = h->have_mech_system = false;
     h->active.valid = false;
     for (bool& f : h->filled) f = false;
+  });
+}
+
+pfv_status pfv_set_periodic(pfv_ctx* h, const int32_t* native_cell, const double* shift) {
+  return guarded(h, [&] {
+    require(h->have_grid, "pfv_set_grid first");
+    require((native_cell == nullptr) == (shift == nullptr), "give both arrays, or neither to clear");
+    h->have_numeric = h->have_system = false;
+    h->rows_complete = false;
+    if (!native_cell) {
+      h->periodic = false;
+      return;
+    }
+    upload(h->face_native, native_cell, (size_t)h->nf, h->stream);
+    upload(h->face_shift, shift, 3 * (size_t)h->nf, h->stream);
+    h->periodic = true;
   });
 }
 

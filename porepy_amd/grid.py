@@ -48,6 +48,19 @@ class Grid:
             bn[fn.indices[fn.indptr[f]: fn.indptr[f + 1]]] = True
         self.tags["domain_boundary_nodes"] = bn
 
+    def set_periodic_map(self, periodic_face_map: np.ndarray) -> None:
+        """Pairs of periodic boundary faces, ``periodic_face_map[0, i]`` with ``[1, i]``; they stop being
+        domain boundary faces (same checks and side effects as grids/grid.py:879-911)."""
+        periodic_face_map = np.asarray(periodic_face_map)
+        if periodic_face_map.shape[0] != 2:
+            raise ValueError("dimension 0 of periodic_face_map must be of size 2")
+        if np.max(periodic_face_map) > self.num_faces:
+            raise ValueError("periodic face number larger than number of faces")
+        if np.min(periodic_face_map) < 0:
+            raise ValueError("periodic face number cannot be negative")
+        self.periodic_face_map = periodic_face_map
+        self.tags["domain_boundary_faces"][self.periodic_face_map.ravel("C")] = False
+
     def get_all_boundary_faces(self) -> np.ndarray:
         t = self.tags
         return np.flatnonzero(t["domain_boundary_faces"] | t["fracture_faces"] | t["tip_faces"])

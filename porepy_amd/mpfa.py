@@ -21,6 +21,7 @@ import numpy as np
 from . import _lib
 from .grid import grid_to_raw
 from .partial import active_indices
+from .periodic import merge_periodic
 from .params import DISCRETIZATION_MATRICES, PARAMETERS, bc_flags
 
 _KEYS = (
@@ -108,6 +109,7 @@ class Mpfa:
         self._contexts: dict = {}
         self._tpfa_discr = None  # grids of dimension < 2
         self._plane: dict = {}  # id(sd) -> (2, 3) in-plane basis of a tilted 2-D grid, or None
+        self._periodic: dict = {}  # id(sd) -> PeriodicMerge of a grid with periodic faces, or None
 
     # ---- Discretization API ---------------------------------------------------------
     def ndof(self, sd) -> int:
@@ -125,8 +127,6 @@ class Mpfa:
         return ent[1]
 
     def _upload_grid(self, ctx, sd):
-        if hasattr(sd, "periodic_face_map"):
-            raise NotImplementedError("periodic faces are not covered")
         raw = grid_to_raw(sd)
         T = None
         if sd.dim == 2:
@@ -140,7 +140,16 @@ class Mpfa:
                     loc[:2] = T @ raw[k]
                     raw[k] = loc
         self._plane[id(sd)] = T
+        merge = None
+        if hasattr(sd, "periodic_face_map"):
+            # periodic faces: discretize the merged grid, copy the rows of the left faces to the
+            # right faces afterwards (_fvutils.py:91-137, mpfa.py:900-917; periodic.py)
+            merge = merge_periodic(raw, sd.periodic_face_map)
+            raw = merge.raw
+        self._periodic[id(sd)] = merge
         ctx.set_grid(raw)
+        if merge is not None:
+            ctx.set_periodic(merge.native, merge.shift)
 
     def _tpfa(self):
         if self._tpfa_discr is None:
@@ -183,6 +192,9 @@ class Mpfa:
             eta = 0.0
         ctx = self.context(sd)
         T = self._plane.get(id(sd))
+        merge = self._periodic.get(id(sd))
+        if merge is not None and (partial or update or subface):
+            raise NotImplementedError("periodic faces: full discretization with conditions per face only")
         kval = np.asarray(k.values, dtype=float)
         if T is not None:
             if vdim != 3:
@@ -232,6 +244,8 @@ class Mpfa:
             lift = sps.kron(sps.identity(sd.num_cells, format="csr"), sps.csr_matrix(basis), format="csr")
         for name, which in _KEYS:
             new = ctx.matrix(which, rows=rows)
+            if merge is not None:
+                new = merge.copy_rows(new, trace=name.startswith("bound_pressure"))
             if lift is not None and "vector_source" in name:
                 new = (new @ lift).tocsr()
                 new.sort_indices()

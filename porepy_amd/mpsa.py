@@ -58,6 +58,9 @@ class Mpsa:
         if np.asarray(bnd.is_dir).ndim != 2:
             # same failure mode as the reference (mpsa.py:658-659)
             raise AttributeError("MPSA must be given a vectorial boundary condition")
+        if hasattr(sd, "periodic_face_map"):
+            # as the reference (mpsa.py:661-664)
+            raise NotImplementedError("Periodic boundary conditions are not implemented for Mpsa")
         basis = getattr(bnd, "basis", None)
         if basis is not None and np.asarray(basis).ndim != 3:
             basis = None

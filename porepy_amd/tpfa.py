@@ -8,6 +8,7 @@ import scipy.sparse as sps
 
 from . import _lib
 from .grid import grid_to_raw
+from .periodic import merge_periodic
 from .params import DISCRETIZATION_MATRICES, PARAMETERS, bc_flags
 
 _KEYS = (
@@ -47,6 +48,7 @@ class Tpfa:
         self.vector_source_matrix_key = "vector_source"
         self.bound_pressure_vector_source_matrix_key = "bound_pressure_vector_source"
         self._contexts: dict = {}
+        self._periodic: dict = {}  # id(sd) -> PeriodicMerge or None
 
     def ndof(self, sd) -> int:
         return sd.num_cells
@@ -55,7 +57,17 @@ class Tpfa:
         ent = self._contexts.get(id(sd))
         if ent is None or ent[0] is not sd:
             ctx = _lib.Context(self.device, self._library)
-            ctx.set_grid(grid_to_raw(sd))
+            raw = grid_to_raw(sd)
+            merge = None
+            if hasattr(sd, "periodic_face_map"):
+                # the cells across a periodic pair become neighbours over the left face
+                # (tpfa.py:114-262); see periodic.py
+                merge = merge_periodic(raw, sd.periodic_face_map)
+                raw = merge.raw
+            self._periodic[id(sd)] = merge
+            ctx.set_grid(raw)
+            if merge is not None:
+                ctx.set_periodic(merge.native, merge.shift)
             self._contexts[id(sd)] = (sd, ctx)
             return ctx
         return ent[1]
@@ -67,8 +79,6 @@ class Tpfa:
         if sd.dim == 0:
             md.update(empty_matrices(sd, vdim))
             return
-        if hasattr(sd, "periodic_face_map"):
-            raise NotImplementedError("periodic faces are not covered")
         if data.get("Aavatsmark_transmissibilities", False):
             raise NotImplementedError("Aavatsmark_transmissibilities is not covered")
         if not 1 <= vdim <= 3:
@@ -77,8 +87,9 @@ class Tpfa:
         bnd = pd["bc"]
         ctx.set_params(np.asarray(pd["second_order_tensor"].values, dtype=float), bc_flags(bnd), None, 0.0, None)
         ctx.tpfa_discretize(vdim)
+        merge = self._periodic.get(id(sd))
         for name, which in _KEYS:
-            md[name] = ctx.matrix(which)
+            md[name] = ctx.matrix(which) if merge is None else merge.copy_rows(ctx.matrix(which))
 
     def update_discretization(self, sd, data: dict) -> None:
         self.discretize(sd, data)

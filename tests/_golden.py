@@ -20,7 +20,7 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "partial_", "tilted_", "tpfa_", "biot_", "subface_"))]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "partial_", "tilted_", "tpfa_", "biot_", "subface_", "periodic_"))]
 
 
 def mpsa_case_names():
@@ -251,3 +251,28 @@ class SubfaceCase:
         for k in ALL_KEYS:
             shape = tuple(int(v) for v in z[f"ref_{k}_shape"])
             self.ref[k] = sps.csr_matrix((z[f"ref_{k}_data"], z[f"ref_{k}_indices"], z[f"ref_{k}_indptr"]), shape=shape)
+
+
+class PeriodicCase:
+    """Grid with periodic faces; Mpfa and Tpfa matrices of the reference (oracle/gen_golden_periodic.py)."""
+
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.grid["name"] = str(self.grid["name"])
+        self.bc = {k[3:]: z[k] for k in z.files if k.startswith("bc_") and k != "bc_values"}
+        self.perm, self.bc_values = z["perm"], z["bc_values"]
+        self.vector_source_values = z["vector_source_values"]
+        self.periodic_face_map = z["periodic_face_map"]
+        self.ref, self.tpfa = {}, {}
+        for tag, out in (("ref_", self.ref), ("tpfa_", self.tpfa)):
+            for k in ALL_KEYS + ("A",):
+                shape = tuple(int(v) for v in z[f"{tag}{k}_shape"])
+                out[k] = sps.csr_matrix((z[f"{tag}{k}_data"], z[f"{tag}{k}_indices"], z[f"{tag}{k}_indptr"]), shape=shape)
+            out["rhs"] = z[tag + "rhs"]
+
+
+def periodic_case_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("periodic_") and f.endswith(".npz"))

@@ -6,7 +6,7 @@ import pytest
 
 import porepy_amd as pa
 from tests import _parity as P
-from tests._golden import case_names
+from tests._golden import periodic_case_names, case_names
 
 
 @pytest.fixture(scope="module")
@@ -124,10 +124,6 @@ def test_error_behaviour_matches_reference(lib):
     ctx = pa.Context(0, lib)
     with pytest.raises(pa.PorefvError):
         ctx.discretize()
-    # periodic faces are refused, not silently ignored
-    g.periodic_face_map = np.array([[0], [3]])
-    with pytest.raises(NotImplementedError):
-        pa.Mpfa("flow", library=lib).discretize(g, data)
 
 
 def test_rediscretize_with_new_parameters_reuses_topology(lib):
@@ -231,3 +227,28 @@ def test_boundary_conditions_per_subface(lib, name, scramble):
 def test_device_resident_vectors(lib):
     g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([4, 4, 4], [1, 1, 1])), 0.03)
     P.device_resident_vectors(lib, g)
+
+
+@pytest.mark.parametrize("scheme", ["mpfa", "tpfa"])
+@pytest.mark.parametrize("name", periodic_case_names())
+def test_periodic_faces(lib, name, scheme):
+    P.check_periodic_case(lib, name, scheme)
+
+
+def test_periodic_faces_error_behaviour(lib):
+    g = _geo(pa.CartGrid([3, 3], [1, 1]))
+    g.set_periodic_map(np.array([[13, 12, 14], [21, 22, 23]]))  # not sorted: as _fvutils.py:103-112
+    K = pa.SecondOrderTensor(np.ones(g.num_cells))
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": pa.BoundaryCondition(g)})
+    with pytest.raises(NotImplementedError):
+        pa.Mpfa("flow", library=lib).discretize(g, data)
+    g = _geo(pa.CartGrid([3, 3], [1, 1]))
+    g.set_periodic_map(np.array([[21, 22, 23], [12, 13, 14]]))  # left faces on the higher cells
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": pa.BoundaryCondition(g)})
+    with pytest.raises(NotImplementedError):
+        pa.Mpfa("flow", library=lib).discretize(g, data)
+    bcv = pa.BoundaryConditionVectorial(g)
+    C = pa.FourthOrderTensor(np.ones(g.num_cells), np.ones(g.num_cells))
+    data = pa.initialize_data({}, "mech", {"fourth_order_tensor": C, "bc": bcv})
+    with pytest.raises(NotImplementedError):  # mpsa.py:661-664
+        pa.Mpsa("mech", library=lib).discretize(g, data)

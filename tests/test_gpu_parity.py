@@ -268,3 +268,10 @@ def test_device_resident_vectors(lib):
 
     g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([6, 6, 6], [1, 1, 1])), 0.03)
     P.device_resident_vectors(lib, g, to_device, lambda t: t.cpu().numpy())
+
+
+@pytest.mark.parametrize("scheme", ["mpfa", "tpfa"])
+@pytest.mark.parametrize("name", ["periodic_cart2d_3x3_both", "periodic_cart2d_4x5_aniso", "periodic_tri2d_4x4",
+                                  "periodic_cart3d_3x3x3_z", "periodic_tet3d_2x2x3_z"])
+def test_periodic_faces(lib, name, scheme):
+    P.check_periodic_case(lib, name, scheme)
