@@ -187,6 +187,16 @@ enum {
 /* coupling tensors as SecondOrderTensor.values, shape (nalpha, 3, 3, Nc) C-order; nalpha = 0
  * switches the coupling terms off.  Needs the grid and pfv_mpsa_set_params. */
 pfv_status pfv_biot_set_alphas(pfv_ctx* h, int nalpha, const double* alpha_k33n);
+/* Partial discretization / update of the coupling terms (biot.py:151-245 update_discretization,
+ * :326-345 specified_cells / faces / nodes): the interaction regions of the nodes of `faces` are
+ * recomputed; face rows (stress, bound_stress, traces, scalar_gradient, bound_displacement_pressure)
+ * of `faces` and cell rows (displacement_divergence, boundary_displacement_divergence, consistency) of
+ * `cells` are rewritten - the caller passes cells all of whose nodes are among the nodes of `faces`,
+ * so that their rows are complete.  keep_other_rows = 0: every other row becomes zero (partial
+ * discretization); 1: they keep their values (update). */
+pfv_status pfv_biot_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces, const int32_t* faces,
+                                     int64_t n_cells, const int32_t* cells, int keep_other_rows);
+
 /* Biot._local_discretization (biot.py:714-878): pfv_mpsa_discretize plus the coupling terms */
 pfv_status pfv_biot_discretize(pfv_ctx* h, uint32_t flags);
 pfv_status pfv_biot_matrix_info(pfv_ctx* h, int term, int64_t* nrows, int64_t* ncols, int64_t* nnz);

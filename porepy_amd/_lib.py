@@ -37,7 +37,7 @@ EXPORTS = [
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
     "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
-    "pfv_set_vectors_on_device", "pfv_set_periodic",
+    "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces",
 ]
 
 
@@ -114,6 +114,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_amg_setup.restype = C.c_int
     lib.pfv_amg_apply_device.argtypes = [_h, C.c_void_p, C.c_void_p]
     lib.pfv_amg_apply_device.restype = C.c_int
+    lib.pfv_biot_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int64, _ip, C.c_int]
+    lib.pfv_biot_discretize_faces.restype = C.c_int
     lib.pfv_set_periodic.argtypes = [_h, C.POINTER(C.c_int32), _dp]
     lib.pfv_set_periodic.restype = C.c_int
     lib.pfv_set_vectors_on_device.argtypes = [_h, C.c_int]
@@ -212,6 +214,7 @@ class Context:
         self.nd = self.nc = self.nf = self.nn = 0
         self._discretized = False  # a complete MPFA discretization is resident on the device
         self._discretized_m = False  # ... MPSA
+        self._discretized_b = False  # ... Biot coupling terms
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -232,6 +235,7 @@ class Context:
     def set_grid(self, raw: dict):
         self._discretized = False
         self._discretized_m = False
+        self._discretized_b = False
         nd = int(raw["dim"])
         nodes = _f64(raw["nodes"]); fn_ = _f64(raw["face_normals"]); fc = _f64(raw["face_centers"])
         cc = _f64(raw["cell_centers"]); fa = _f64(raw["face_areas"])
@@ -322,6 +326,20 @@ class Context:
     def biot_discretize(self, rebuild_topology=False):
         self._check(self.lib.pfv_biot_discretize(self._h, DISCR_REBUILD_TOPOLOGY if rebuild_topology else 0))
         self._discretized_m = True
+        self._discretized_b = True
+
+    def biot_discretize_faces(self, faces, cells, keep_other_rows: bool):
+        """Partial discretization / update of MPSA + coupling terms (include/porefv.h)."""
+        fa = np.ascontiguousarray(faces, dtype=np.int32)
+        ce = np.ascontiguousarray(cells, dtype=np.int32)
+        self._check(self.lib.pfv_biot_discretize_faces(self._h, 0, fa.size, _ptr(fa, _ip), ce.size, _ptr(ce, _ip),
+                                                       1 if keep_other_rows else 0))
+        self._discretized_m = self._discretized_m and bool(keep_other_rows)
+        self._discretized_b = self._discretized_b and bool(keep_other_rows)
+
+    @property
+    def has_biot_discretization(self) -> bool:
+        return self._discretized_b
 
     def biot_matrix(self, term: int, key: int):
         import scipy.sparse as sps

@@ -11,6 +11,7 @@ import numpy as np
 
 from . import _lib
 from .mpfa import determine_eta
+from .partial import active_indices
 from .mpsa import Mpsa
 from .mpsa import _KEYS as _MECH_KEYS
 from .params import DISCRETIZATION_MATRICES, PARAMETERS, SecondOrderTensor
@@ -42,9 +43,9 @@ class Biot(Mpsa):
     def discretize(self, sd, data: dict) -> None:
         pd = data[PARAMETERS][self.keyword]
         md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
-        for key in ("specified_cells", "specified_faces", "specified_nodes"):
-            if pd.get(key) is not None:
-                raise NotImplementedError("partial discretization of the coupling terms is not covered")
+        spec = [pd.get(k) for k in ("specified_cells", "specified_faces", "specified_nodes")]
+        partial = any(v is not None for v in spec)
+        update = bool(pd.get("update_discretization", False))
         C = pd["fourth_order_tensor"]
         bnd = pd["bc"]
         if np.asarray(bnd.is_dir).ndim != 2:
@@ -69,8 +70,31 @@ class Biot(Mpsa):
                             robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None,
                             basis=basis)
         ctx.biot_set_alphas(alphas)
+        if partial and not alphas:
+            return Mpsa.discretize(self, sd, data)
+        active_cells, active_faces = np.arange(sd.num_cells), np.arange(sd.num_faces)
         try:
-            if alphas:
+            if partial:
+                # Node-list launch around the active faces (biot.py:326-345, 400-560: the reference
+                # discretizes the sub-grid of the active cells and keeps the rows of the active faces
+                # / cells).  Face rows are complete for the active faces.  A cell row sums over the
+                # nodes of the cell: it is complete for cells all of whose nodes were recomputed -
+                # only those are written (the reference's rows of the other active cells carry the
+                # artificial boundary of its sub-grid); under an update the nodes that were not
+                # recomputed still hold their tables, so every cell touching a recomputed node is
+                # rewritten.
+                active_cells, active_faces = active_indices(sd, *spec)
+                keep = update and ctx.has_biot_discretization
+                fn = sd.face_nodes.tocsc()
+                mark = np.zeros(sd.num_nodes)
+                for f in active_faces:
+                    mark[fn.indices[fn.indptr[f]: fn.indptr[f + 1]]] = 1.0
+                cn = sd.cell_nodes().astype(float)  # (Nn, Nc)
+                hit = np.asarray(cn.T @ mark).ravel()
+                tot = np.asarray(cn.sum(axis=0)).ravel()
+                cells = np.flatnonzero(hit > 0) if keep else np.flatnonzero(hit == tot)
+                ctx.biot_discretize_faces(active_faces, cells, keep_other_rows=keep)
+            elif alphas:
                 ctx.biot_discretize()
             else:
                 ctx.mpsa_discretize()
@@ -84,9 +108,10 @@ class Biot(Mpsa):
             md[name] = ctx.matrix(which)
         for name, term in _TERMS:
             md[name] = {k: ctx.biot_matrix(term, i) for i, k in enumerate(keys)}
+        pd["active_cells"] = active_cells
+        pd["active_faces"] = active_faces
 
-    def update_discretization(self, sd, data: dict) -> None:
-        self.discretize(sd, data)
+    # update_discretization: Mpsa's (modified_cells / modified_faces -> specified_* + update flag)
 
 
 def as_porepy_biot(device: int = 0, library=None):

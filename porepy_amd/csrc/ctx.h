@@ -110,6 +110,8 @@ struct pfv_ctx_impl {
   Buf<uint8_t> flux_colpairs; // [nnz(flux) * max_face_nodes] for every flux column: the (node of face, cell) pair per node, 0xff = none
   Buf<uint8_t> node_active;   // [nn] partial discretization: nodes of the requested faces
   Buf<int32_t> face_subset;   // partial discretization: the requested faces
+  bool biot_rows_complete = false;  // every row of the coupling terms holds a current value (updates need it)
+  Buf<int32_t> cell_subset;   // pfv_biot_discretize_faces: cells whose rows are recomputed
   Buf<int32_t> face_order;    // [nf] faces along a Morton curve of their centres: processing order of the
                               //      face kernels, so that faces sharing nodes run close in time (L2 reuse)
   double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {1, 1, 1};

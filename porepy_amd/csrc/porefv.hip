@@ -178,6 +178,7 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     h->perm_for_val = nullptr;
     h->win_for = h->win_rows_for = nullptr;
     h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
+    h->biot_rows_complete = false;
     h->rows_complete = false;
     h->rows_complete_m = false;
     h->have_sub_symbolic = false;
@@ -582,6 +583,7 @@ pfv_status pfv_biot_set_alphas(pfv_ctx* h, int nalpha, const double* alpha_k33n)
     if (layout_change) {
       h->have_mpsa_symbolic = false;  // LDS sizing of the node kernel depends on it
       h->have_biot_symbolic = false;
+      h->biot_rows_complete = false;
     }
     h->have_biot_numeric = false;
   });
@@ -622,8 +624,47 @@ pfv_status pfv_biot_discretize(pfv_ctx* h, uint32_t flags) {
     h->have_mpsa_numeric = true;
     h->rows_complete_m = true;
     h->have_biot_numeric = true;
+    h->biot_rows_complete = true;
     h->have_mech_system = false;
     h->filled[PFV_MAT_MECH_SYSTEM] = false;
+  });
+}
+
+pfv_status pfv_biot_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces, const int32_t* faces,
+                                     int64_t n_cells, const int32_t* cells, int keep_other_rows) {
+  if (!h) return PFV_ERR_ARGUMENT;
+  if (keep_other_rows && !h->biot_rows_complete) {
+    h->err = "update of coupling terms that were never computed on this handle";
+    return PFV_ERR_ARGUMENT;
+  }
+  if (h->biot_nalpha <= 0) {
+    h->err = "pfv_biot_set_alphas first";
+    return PFV_ERR_ARGUMENT;
+  }
+  // interaction regions of the faces' nodes (with the Biot tail) and the four MPSA matrices
+  pfv_status st = pfv_mpsa_discretize_faces(h, flags, n_faces, faces, keep_other_rows);
+  if (st != PFV_OK) return st;
+  return guarded(h, [&] {
+    require(n_cells >= 0 && (n_cells == 0 || cells), "bad cell list");
+    for (int64_t i = 0; i < n_cells; ++i) require(cells[i] >= 0 && cells[i] < h->nc, "cell index out of range");
+    auto s = h->stream;
+    int32_t* csub = h->cell_subset.ensure(std::max<int64_t>(n_cells, 1));
+    pfv::be_h2d(csub, cells, sizeof(int32_t) * (size_t)n_cells, s);
+    if (!keep_other_rows) {
+      for (int term = 0; term < PFV_BIOT_NUM_TERMS; ++term) {
+        const int64_t nnz = pfv::biot_pattern(*h, term).nnz;
+        for (int ka = 0; ka < h->biot_nalpha; ++ka) {
+          double* v = h->biot_val[(size_t)term * h->biot_nalpha + ka].ensure(std::max<int64_t>(nnz, 1));
+          pfv::be_memset(v, 0, sizeof(double) * (size_t)nnz, s);
+        }
+      }
+    }
+    for (int ka = 0; ka < h->biot_nalpha; ++ka) {
+      if (n_faces > 0) pfv::biot_run_face_kernel(*h, ka, h->face_subset.p, n_faces);
+      if (n_cells > 0) pfv::biot_run_cell_kernel(*h, ka, csub, n_cells);
+    }
+    if (!keep_other_rows) h->biot_rows_complete = false;
+    h->have_biot_numeric = true;
   });
 }
 

@@ -688,3 +688,74 @@ def check_periodic_case(lib, name: str, scheme: str = "mpfa"):
         x, info = d.solve(g, data, source=src, method="bicgstab", rtol=1e-13)
         xo = spla.spsolve(ref["A"].tocsc(), ref["rhs"] + src)
         assert np.linalg.norm(x - xo) <= TOL * np.linalg.norm(xo)
+
+
+def check_biot_partial_case(lib, name: str):
+    """Partial discretization of the Biot terms around the nodes of one cell (the reference's own
+    test, tests/numerics/fv/test_biot.py:88-198: rows of the active faces / of the cell equal the full
+    discretization, every row outside the active sets is zero), then an update after a parameter
+    change against a fresh full discretization."""
+    c = BiotCase(name)
+    g = pa.grid_from_raw(c.grid)
+    nd = g.dim
+
+    def make(stiff, alphas):
+        bc = pa.BoundaryConditionVectorial(g)
+        bc.is_dir, bc.is_neu, bc.is_rob = c.bc["is_dir"].copy(), c.bc["is_neu"].copy(), c.bc["is_rob"].copy()
+        bc.robin_weight = c.bc["robin_weight"]
+        C = type("C", (), {"values": stiff})()
+        maps = {k: type("A", (), {"values": v})() for k, v in alphas.items()}
+        return pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "scalar_vector_mappings": maps})
+
+    cn = g.cell_nodes().tocsc()
+    face_keys = ("scalar_gradient", "bound_displacement_pressure")
+    cell_keys = ("displacement_divergence", "boundary_displacement_divergence", "mpsa_consistency")
+    for cell in (0, g.num_cells // 2, g.num_cells - 1):
+        data = make(c.stiffness, c.alphas)
+        data[pa.PARAMETERS]["mechanics"]["specified_nodes"] = cn.indices[cn.indptr[cell]: cn.indptr[cell + 1]]
+        d = pa.Biot("mechanics", library=lib)
+        d.discretize(g, data)
+        md = data[pa.DISCRETIZATION_MATRICES]["mechanics"]
+        af = data[pa.PARAMETERS]["mechanics"]["active_faces"]
+        ac = data[pa.PARAMETERS]["mechanics"]["active_cells"]
+        assert cell in ac
+        rows_f = (nd * af[:, None] + np.arange(nd)[None, :]).ravel()
+        off_f = np.setdiff1d(np.arange(nd * g.num_faces), rows_f)
+        off_c = np.setdiff1d(np.arange(g.num_cells), ac)
+        for k in ("stress", "bound_stress"):
+            assert rel_max_err(md[k][rows_f], c.ref_mech[k][rows_f]) < TOL, (name, k)
+            assert abs(md[k][off_f]).max() == 0
+        for key in c.alphas:
+            for k in face_keys:
+                assert rel_max_err(md[k][key][rows_f], c.ref[k][key][rows_f]) < TOL, (name, k, key, cell)
+                assert abs(md[k][key][off_f]).max() == 0
+            for k in cell_keys:
+                assert rel_max_err(md[k][key][[cell]], c.ref[k][key][[cell]]) < TOL, (name, k, key, cell)
+                if off_c.size:
+                    assert abs(md[k][key][off_c]).max() == 0
+    # update: new parameters in one cell, rediscretize around it, compare with a full discretization
+    rng = np.random.default_rng(5)
+    data = make(c.stiffness, c.alphas)
+    d = pa.Biot("mechanics", library=lib)
+    d.discretize(g, data)
+    cell = g.num_cells // 3
+    stiff2 = c.stiffness.copy()
+    stiff2[..., cell] *= 1.7
+    alphas2 = {k: v.copy() for k, v in c.alphas.items()}
+    for v in alphas2.values():
+        v[..., cell] *= 0.6
+    pd = data[pa.PARAMETERS]["mechanics"]
+    pd["fourth_order_tensor"] = type("C", (), {"values": stiff2})()
+    pd["scalar_vector_mappings"] = {k: type("A", (), {"values": v})() for k, v in alphas2.items()}
+    data["update_discretization"] = {"modified_cells": np.array([cell])}
+    d.update_discretization(g, data)
+    md = data[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    full = make(stiff2, alphas2)
+    pa.Biot("mechanics", library=lib).discretize(g, full)
+    mf = full[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    for k in ("stress", "bound_stress", "bound_displacement_cell", "bound_displacement_face"):
+        assert rel_max_err(md[k], mf[k]) < 1e-12, (name, k)
+    for k in face_keys + cell_keys:
+        for key in c.alphas:
+            assert rel_max_err(md[k][key], mf[k][key]) < 1e-12, (name, k, key)
+    assert rng is not None

@@ -100,3 +100,8 @@ def test_rotated_boundary_basis_gives_the_same_solution(lib):
         u, info = d.solve(g, data, rtol=1e-13)
         sols.append(u)
     assert np.linalg.norm(sols[0] - sols[1]) <= 1e-9 * np.linalg.norm(sols[0])
+
+
+@pytest.mark.parametrize("name", ["biot_tri2d_3x3_mixed", "biot_tet_2x2x2_mixed"])
+def test_biot_partial_discretization_and_update(lib, name):
+    P.check_biot_partial_case(lib, name)
