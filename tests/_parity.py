@@ -9,6 +9,7 @@ import sys
 import numpy as np
 import pytest
 import scipy.sparse.linalg as spla
+from scipy.sparse import csr_matrix as sps_csr
 
 import porepy_amd as pa
 from oracle import mpfa_oracle as mo
@@ -759,3 +760,145 @@ def check_biot_partial_case(lib, name: str):
         for key in c.alphas:
             assert rel_max_err(md[k][key], mf[k][key]) < 1e-12, (name, k, key)
     assert rng is not None
+
+
+def full_size_patch_parity(lib, n_side: int = 69, seeds=(0, None, -1)):
+    """Parity at the benchmark's full size (BASELINE configs[2], 1 971 054 tetrahedra) where the oracle
+    cannot run on the whole grid: rows of the device matrices of the *full* problem against the oracle
+    run on patches cut out of it.  A face row only involves the interaction regions of the face's
+    nodes, so on a patch = some cells + one node-ring of halo cells (distributed.extract_subdomain)
+    the oracle's rows of the faces of the inner cells are the global rows; the same for the rows of
+    A = div flux of the inner cells.  Plus the size-independent checks: the solve's true residual in
+    the device system and constant pressure -> zero flux."""
+    import bench
+    from porepy_amd import distributed as D
+
+    g, K, bc, bv, src = bench.make_problem(n_side)
+    raw = pa.grid_to_raw(g)
+    nc, nf = g.num_cells, g.num_faces
+    flags = pa.bc_flags(bc)
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(raw)
+    ctx.set_params(K.values, flags, bc.robin_weight, pa.determine_eta(g))
+    ctx.discretize(skip_vector_source=True)
+    ctx.assemble(bv, None, src)
+    x, info = ctx.solve("bicgstab", rtol=1e-11, precond="amg")
+    assert info["converged"]
+    A = ctx.matrix(pa._lib.MAT_SYSTEM)
+    b = ctx.rhs()
+    assert np.linalg.norm(b - A @ x) <= 1e-10 * np.linalg.norm(b)
+    flux = ctx.matrix(pa._lib.MAT_FLUX)
+    bflux = ctx.matrix(pa._lib.MAT_BOUND_FLUX)
+    ones_f = np.asarray(bc.is_dir, dtype=float)  # p = 1 on the Dirichlet faces, zero Neumann flux
+    q = flux @ np.ones(nc) + bflux @ ones_f
+    assert np.max(np.abs(q)) < 1e-10 * abs(flux).max()
+    cn = g.cell_nodes().tocsc()   # (Nn, Nc)
+    nodes_cells = cn.tocsr()
+    rng = np.random.default_rng(3)
+    raw_bc = pa.params.bc_to_raw(bc)
+    checked = 0
+    for seed in seeds:
+        c0 = {0: 0, -1: nc - 1}.get(seed, int(rng.integers(nc)))
+        inner = np.unique(nodes_cells[cn.indices[cn.indptr[c0]: cn.indptr[c0 + 1]]].indices)  # cells around c0
+        owner = np.ones(nc, dtype=np.int32)
+        owner[inner] = 0
+        lp = D.extract_subdomain(raw, owner, 0)
+        lbc = {k: np.asarray(raw_bc[k])[lp.face_gid].copy() for k in ("is_dir", "is_neu", "is_rob", "is_internal")}
+        lbc["robin_weight"] = np.asarray(raw_bc["robin_weight"], dtype=float)[lp.face_gid]
+        art = lp.artificial_boundary
+        lbc["is_dir"][art] = False
+        lbc["is_rob"][art] = False
+        lbc["is_neu"][art] = True
+        ora = mo.discretize(lp.raw, np.ascontiguousarray(K.values[:, :, lp.cell_gid]), lbc, eta=pa.determine_eta(g))
+        # faces of the inner cells, in local and global numbering
+        lcf = lp.raw["cf_indices"][: lp.raw["cf_indptr"][lp.n_own]]
+        lfaces = np.unique(lcf)
+        gfaces = lp.face_gid[lfaces]
+        col_map = np.full(nc, -1)
+        col_map[lp.cell_gid] = np.arange(lp.cell_gid.size)
+        fmap = np.full(nf, -1)
+        fmap[lp.face_gid] = np.arange(lp.face_gid.size)
+        for name, M, cmap in (("flux", flux, col_map), ("bound_flux", bflux, fmap)):
+            G = M[gfaces].tocoo()
+            assert np.all(cmap[G.col] >= 0), name  # the global rows stay inside the patch
+            Gl = sps_csr((G.data, (G.row, cmap[G.col])), shape=(gfaces.size, ora[name].shape[1]))
+            assert rel_max_err(Gl, ora[name][lfaces]) < TOL, (name, seed)
+        Aora, _ = mo.assemble_matrix_rhs(lp.raw, ora, np.zeros(lp.face_gid.size))
+        G = A[lp.cell_gid[: lp.n_own]].tocoo()
+        assert np.all(col_map[G.col] >= 0)
+        Gl = sps_csr((G.data, (G.row, col_map[G.col])), shape=(lp.n_own, lp.cell_gid.size))
+        assert rel_max_err(Gl, Aora[: lp.n_own]) < TOL, ("A", seed)
+        checked += lfaces.size
+    return {"iterations": info["iterations"], "rows_checked": checked}
+
+
+def full_size_patch_parity_mpsa(lib, n_side: int = 44, seeds=(0, None, -1)):
+    """The same for the elasticity path at BASELINE configs[3] (511 104 tetrahedra, 1.53 M dofs):
+    stress / bound_stress rows of the full problem against the MPSA oracle on patches, the exact
+    uniaxial solution, the true residual."""
+    from porepy_amd import distributed as D
+
+    n = n_side
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.2 / n)
+    nc, nf, nd = g.num_cells, g.num_faces, 3
+    rng = np.random.default_rng(6)
+    C = pa.FourthOrderTensor(np.ones(nc), np.ones(nc))
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    fc = g.face_centers
+    for axis in range(3):
+        roll = bf[fc[axis, bf] < 1e-9]
+        bc.is_dir[axis, roll] = True
+        bc.is_neu[axis, roll] = False
+    bv = np.zeros((3, nf))
+    top = bf[fc[2, bf] > 1 - 1e-9]
+    bv[2, top] = -g.face_areas[top]
+    raw = pa.grid_to_raw(g)
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(raw)
+    eta = 1.0 / 3.0
+    ctx.mpsa_set_params(C.values, g.cell_volumes, bc.is_dir, bc.is_neu, eta)
+    ctx.mpsa_discretize()
+    ctx.mpsa_assemble(bv.ravel("F"), None)
+    u, info = ctx.solve("bicgstab", rtol=1e-11, maxit=50000, n=nd * nc, precond="amg")
+    cc = g.cell_centers
+    E, nu = 2.5, 0.25
+    exact = np.vstack((nu * cc[0] / E, nu * cc[1] / E, -cc[2] / E))
+    assert np.max(np.abs(u.reshape(3, -1, order="F") - exact)) < 1e-9
+    A = ctx.matrix(pa._lib.MAT_MECH_SYSTEM)
+    b = ctx.active_rhs(nd * nc)
+    assert np.linalg.norm(b - A @ u) <= 1e-10 * np.linalg.norm(b)
+    stress = ctx.matrix(MPSA_WHICH["stress"])
+    bstress = ctx.matrix(MPSA_WHICH["bound_stress"])
+    cn = g.cell_nodes().tocsc()
+    nodes_cells = cn.tocsr()
+    checked = 0
+    for seed in seeds:
+        c0 = {0: 0, -1: nc - 1}.get(seed, int(rng.integers(nc)))
+        inner = np.unique(nodes_cells[cn.indices[cn.indptr[c0]: cn.indptr[c0 + 1]]].indices)
+        owner = np.ones(nc, dtype=np.int32)
+        owner[inner] = 0
+        lp = D.extract_subdomain(raw, owner, 0)
+        art = lp.artificial_boundary
+        ldir = bc.is_dir[:, lp.face_gid].copy()
+        lneu = bc.is_neu[:, lp.face_gid].copy()
+        ldir[:, art] = False
+        lneu[:, art] = True
+        ora = so.discretize(lp.raw, np.ascontiguousarray(C.values[:, :, lp.cell_gid]), {"is_dir": ldir, "is_neu": lneu}, eta=eta)
+        lcf = lp.raw["cf_indices"][: lp.raw["cf_indptr"][lp.n_own]]
+        lfaces = np.unique(lcf)
+        gfaces = lp.face_gid[lfaces]
+        ex = lambda idx: (nd * np.asarray(idx)[:, None] + np.arange(nd)[None, :]).ravel()  # noqa: E731
+        cmap = np.full(nd * nc, -1)
+        cmap[ex(lp.cell_gid)] = np.arange(nd * lp.cell_gid.size)
+        fmap = np.full(nd * nf, -1)
+        fmap[ex(lp.face_gid)] = np.arange(nd * lp.face_gid.size)
+        for name, M, m in (("stress", stress, cmap), ("bound_stress", bstress, fmap)):
+            G = M[ex(gfaces)].tocoo()
+            assert np.all(m[G.col] >= 0), name
+            Gl = sps_csr((G.data, (G.row, m[G.col])), shape=(nd * gfaces.size, ora[name].shape[1]))
+            assert rel_max_err(Gl, ora[name][ex(lfaces)]) < TOL, (name, seed)
+        checked += lfaces.size
+    return {"iterations": info["iterations"], "rows_checked": checked}

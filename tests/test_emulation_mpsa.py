@@ -108,3 +108,8 @@ def test_rotated_boundary_basis_gives_the_same_solution(lib):
 @pytest.mark.parametrize("name", ["biot_tri2d_3x3_mixed", "biot_cart2d_3x2_dir", "biot_tet_2x2x2_mixed"])
 def test_biot_partial_discretization_and_update(lib, name):
     P.check_biot_partial_case(lib, name)
+
+
+def test_patch_parity_machinery_small(lib):
+    out = P.full_size_patch_parity_mpsa(lib, 4, seeds=(0, None))
+    assert out["rows_checked"] > 20

@@ -252,3 +252,9 @@ def test_periodic_faces_error_behaviour(lib):
     data = pa.initialize_data({}, "mech", {"fourth_order_tensor": C, "bc": bcv})
     with pytest.raises(NotImplementedError):  # mpsa.py:661-664
         pa.Mpsa("mech", library=lib).discretize(g, data)
+
+
+def test_patch_parity_machinery_small(lib):
+    """The full-size GPU test's machinery on a small grid (host emulation)."""
+    out = P.full_size_patch_parity(lib, 6, seeds=(0, None))
+    assert out["rows_checked"] > 20

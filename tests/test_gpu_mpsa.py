@@ -105,3 +105,9 @@ def test_rotated_boundary_basis_gives_the_same_solution(lib):
 @pytest.mark.parametrize("name", ["biot_tri2d_3x3_mixed", "biot_tet_2x2x2_mixed"])
 def test_biot_partial_discretization_and_update(lib, name):
     P.check_biot_partial_case(lib, name)
+
+
+def test_full_size_rows_match_oracle_on_patches(lib):
+    """BASELINE configs[3] at full size (511 104 tetrahedra, 1.53 M dofs)."""
+    out = P.full_size_patch_parity_mpsa(lib, 44)
+    assert out["rows_checked"] > 100

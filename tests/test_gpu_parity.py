@@ -275,3 +275,9 @@ def test_device_resident_vectors(lib):
                                   "periodic_cart3d_3x3x3_z", "periodic_tet3d_2x2x3_z"])
 def test_periodic_faces(lib, name, scheme):
     P.check_periodic_case(lib, name, scheme)
+
+
+def test_full_size_rows_match_oracle_on_patches(lib):
+    """BASELINE configs[2] at full size (1 971 054 tetrahedra, the bench workload)."""
+    out = P.full_size_patch_parity(lib, 69)
+    assert out["rows_checked"] > 100
