@@ -285,6 +285,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # validation hook for boxes with fewer GPUs than ranks (never set by the driver): all ranks share
+    # GPU 0 and talk over gloo, which exercises everything of the N > 1 path except RCCL itself
+    share_gpu = os.environ.get("PFV_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with python -m torch.distributed.run --nproc-per-node N")
@@ -296,7 +301,10 @@ def main():
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:

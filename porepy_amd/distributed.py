@@ -195,20 +195,25 @@ class HaloPlan:
         import torch
 
         dist = self.dist
+        # gloo cannot send / receive device tensors: stage through the host (validation runs only;
+        # the product backend is RCCL, which moves device buffers directly)
+        stage = x_full.is_cuda and dist.get_backend() == "gloo"
+        buf_dev = "cpu" if stage else x_full.device
         ops, rbufs = [], {}
         for q, pos in self.recv.items():
-            rbufs[q] = torch.empty(pos.numel(), dtype=x_full.dtype, device=x_full.device)
+            rbufs[q] = torch.empty(pos.numel(), dtype=x_full.dtype, device=buf_dev)
             ops.append(dist.P2POp(dist.irecv, rbufs[q], q))
         sbufs = []
         for p, idx in self.send.items():
             sb = x_full.index_select(0, idx).contiguous()
+            if stage:
+                sb = sb.cpu()
             sbufs.append(sb)
             ops.append(dist.P2POp(dist.isend, sb, p))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         for q, pos in self.recv.items():
-            x_full.index_copy_(0, pos, rbufs[q])
-
+            x_full.index_copy_(0, pos, rbufs[q].to(x_full.device) if stage else rbufs[q])
 
 # ------------------------------------------------------------------------------------------
 class ShardedMpfa:
