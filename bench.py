@@ -391,6 +391,7 @@ def main():
                    "streamed_GBs": moved / (spmv_ms * 1e-3) / 1e9}
     roofline = krylov_spmv
     roofline_other = None
+    sm_ms = None
     if args.precond == "amg" and os.environ.get("PFV_AMG_FP32", "1") != "0":
         # the V(1,1) cycles run 4 finest-level products per iteration on a single-precision copy of A's
         # values (fused damped-Jacobi update): more total time than the 2 double-precision products
@@ -406,7 +407,7 @@ def main():
                   "bytes_per_launch": sm_bytes, "ms_per_launch": sm_ms,
                   "note": "achieved = CSR bytes with f32 values (8 B per entry) / time; the kernel streams ~6 B per entry",
                   "streamed_GBs": sm_moved / (sm_ms * 1e-3) / 1e9}
-        if 4 * sm_ms > 2 * spmv_ms:
+        if 4 * sm_ms > 2 * spmv_ms:  # (and, with ~18 iterations, more than the face kernel: kernel_ms_per_step)
             roofline, roofline_other = smooth, krylov_spmv
         else:
             roofline_other = smooth
@@ -422,6 +423,24 @@ def main():
                 "phases_ms": {k: st[k] for k in ("topology_ms", "symbolic_ms", "node_ms", "face_ms",
                                                  "assemble_ms", "solve_ms")},
                 "cells_per_s_assembly_only": nloc / (asm_ms * 1e-3)}
+
+    # the assembly kernel with the most time: the face kernel (gathers the per-node tables, writes the
+    # values of the six matrices)
+    face_ms = ctx.time_kernel(2, reps=3)
+    face_bytes = 8.0 * sum(nnz.values())  # every value written once; its inputs are intermediate tables
+    face_pmc = None  # FETCH (doubled per the guide) + WRITE of profiles/r01_pmc_assembly_kernels.txt
+    if args.n_side == 69 and world == 1:
+        face_pmc = (2.117e7 + 1.5e7) * 1024  # counters in KB (FETCH as reported, not doubled: 128-byte table rows)
+    roofline_face = {"bound": "hbm", "kernel": "run_face_kernel (sub-face rows of the node tables -> CSR values of the six matrices)",
+                     "achieved": face_bytes / (face_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": face_bytes / (face_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": face_pmc,
+                     "bytes_per_launch": face_bytes, "ms_per_launch": face_ms,
+                     "note": "1 launch per step; moves 2.5x its algorithmic bytes (the per-node tables are read back from HBM)"}
+    its = int(info["iterations"]) if isinstance(info, dict) and "iterations" in info else 0
+    # time per step by kernel: f32 cycle products (both epilogues of k_spmv_win<float>: 4 per iteration),
+    # f64 products of the Krylov loop (2 per iteration), face kernel (1)
+    per_step_ms = {"amg_f32_products": (4 * its * sm_ms) if sm_ms is not None else 0.0,
+                   "krylov_f64_products": 2 * its * spmv_ms, "face_kernel": face_ms}
 
     cpu = None
     c2 = c4 = None
@@ -466,7 +485,8 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} z-slab subdomains (1 lattice layer of halo cells recomputed per cut), assembly "
                        "without collectives, BiCGStab with RCCL point-to-point halo exchange + fused all-reduces"},
-            "roofline": roofline, "roofline_second_kernel": roofline_other, "assembly": assembly, "cpu_baseline": cpu, "config_c2": c2, "config_c4": c4,
+            "roofline": roofline, "roofline_second_kernel": roofline_other, "roofline_face_kernel": roofline_face,
+            "kernel_ms_per_step": per_step_ms, "assembly": assembly, "cpu_baseline": cpu, "config_c2": c2, "config_c4": c4,
         }
         if args.phases:
             print(json.dumps(st, indent=1), file=sys.stderr)
