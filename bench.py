@@ -158,7 +158,7 @@ def _hash_normal(gid: np.ndarray, salt: int) -> np.ndarray:
     return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
 
 
-def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = None):
+def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = None, strong: bool = False):
     """Rank `rank`'s share of the global box [0,1]x[0,1]x[0,layers*world/n] of n x n x (layers*world) lattice
     cells (6 tetrahedra each): its n lattice layers plus one halo layer on each interior side,
     built directly (no global grid), owned cells numbered first.  Geometry perturbation and the
@@ -168,9 +168,15 @@ def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = N
     from porepy_amd import distributed as D
 
     n = n_side
-    lay = n if layers is None else int(layers)  # lattice layers owned by each rank
-    ktot = lay * world
-    k0, k1 = max(0, rank * lay - 1), min(ktot, (rank + 1) * lay + 1)
+    lay = n if layers is None else int(layers)  # lattice layers owned by each rank (weak scaling)
+    ktot = n if strong else lay * world
+    # layer boundaries of the ranks: weak = `lay` layers each (the box grows with the number of ranks),
+    # strong = the n layers of the one-GPU box split as evenly as possible
+    bounds = np.array([(r * ktot) // world for r in range(world + 1)]) if strong else lay * np.arange(world + 1)
+    if np.any(np.diff(bounds) < 1):
+        raise SystemExit("more ranks than lattice layers")
+    lo_k, hi_k = int(bounds[rank]), int(bounds[rank + 1])
+    k0, k1 = max(0, lo_k - 1), min(ktot, hi_k + 1)
     nl = k1 - k0
     g = pa.StructuredTetrahedralGrid([n, n, nl], [1.0, 1.0, nl / n])
     x = g.nodes.copy()
@@ -196,7 +202,7 @@ def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = N
     ci, cj, ckl = cube % n, (cube // n) % n, cube // (n * n)
     ckg = ckl + k0
     cgid = t + 6 * (ci + n * (cj + n * ckg))
-    owned = (ckg >= rank * lay) & (ckg < (rank + 1) * lay)
+    owned = (ckg >= lo_k) & (ckg < hi_k)
     # local numbering: owned cells first, each group along a Morton curve (locality of the SpMV gathers)
     io, ih = np.flatnonzero(owned), np.flatnonzero(~owned)
     io = io[D.morton_order(raw["cell_centers"][:, io], 3)]
@@ -213,7 +219,7 @@ def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = N
     on_top_cut = np.all(fkl == nl, axis=1) & (k1 < ktot)
     artificial = (sides == 1) & (on_bottom_cut | on_top_cut)
     lp = D.LocalProblem(raw=raw, n_own=n_own, cell_gid=cgid.astype(np.int64),
-                        halo_owner=(ckg[n_own:] // lay).astype(np.int32), face_gid=None,
+                        halo_owner=(np.searchsorted(bounds, ckg[n_own:], side="right") - 1).astype(np.int32), face_gid=None,
                         artificial_boundary=artificial)
     # parameters: full-tensor anisotropic K times a log-normal field; Dirichlet p = x on x-faces
     scale = np.exp(0.5 * _hash_normal(cgid, 7))
@@ -274,6 +280,9 @@ def main():
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the secondary lines for BASELINE configs[1] and configs[3] (profiling runs)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): every GPU owns an n x n x n lattice slab of a box that grows with N; "
+                         "strong: the one-GPU box split into N slabs")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (torch-driven sharded solver) on one GPU, for validation")
     args = ap.parse_args()
@@ -313,7 +322,7 @@ def main():
 
     from porepy_amd import distributed as D
 
-    lp, Kvals, flags, bv, src, eta = make_slab_problem(args.n_side, rank, world)
+    lp, Kvals, flags, bv, src, eta = make_slab_problem(args.n_side, rank, world, strong=args.scaling == "strong")
     nc = lp.n_own                      # cells this rank owns (halo cells are recomputed, not counted)
     nloc = lp.raw["cell_centers"].shape[1]
     if world == 1 and not args.force_sharded:
@@ -469,7 +478,7 @@ def main():
         line = {
             "metric": "cells/sec MPFA assemble+solve, 3D unstructured grid",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2] (the 2 M-cell grid the north_star target is quoted on): "
                                    f"3D simplex box, {nc} owned tetrahedra per GPU (n_side={args.n_side}), perturbed "

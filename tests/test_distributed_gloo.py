@@ -120,7 +120,7 @@ def test_halo_plan_single_rank_is_noop():
     assert plan.bytes_per_exchange == 0
 
 
-def _slab_worker(rank, world, port, out):
+def _slab_worker(rank, world, port, out, strong=False):
     import torch
     import torch.distributed as dist
 
@@ -131,7 +131,10 @@ def _slab_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lib = P.emulation_library()
-        lp, Kv, flags, bv, src, eta = bench.make_slab_problem(4, rank, world, layers=3)
+        if strong:  # the 7-layer one-rank box split 2 + 2 + 3
+            lp, Kv, flags, bv, src, eta = bench.make_slab_problem(7, rank, world, strong=True)
+        else:
+            lp, Kv, flags, bv, src, eta = bench.make_slab_problem(4, rank, world, layers=3)
         sh = D.ShardedMpfa(lp, device="cpu", library=lib, dist=dist)
         sh.discretize(Kv, flags, None, eta)
         sh.assemble(bv, src)
@@ -141,9 +144,11 @@ def _slab_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_bench_slab_decomposition_matches_single_domain(tmp_path):
+@pytest.mark.parametrize("strong", [False, True])
+def test_bench_slab_decomposition_matches_single_domain(tmp_path, strong):
     """The slab problems bench.py builds per rank (no global grid) are one global problem:
-    3 ranks x 3 lattice layers reproduce the 9-layer single-domain solution."""
+    3 ranks x 3 lattice layers reproduce the 9-layer single-domain solution (weak scaling); the
+    7-layer box of one rank split 2 + 2 + 3 reproduces itself (--scaling strong)."""
     import torch
     import torch.multiprocessing as mp
 
@@ -151,9 +156,12 @@ def test_bench_slab_decomposition_matches_single_domain(tmp_path):
 
     world = 3
     P.emulation_library()  # build once here, not concurrently in the workers
-    mp.spawn(_slab_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_slab_worker, args=(world, _free_port(), str(tmp_path), strong), nprocs=world, join=True)
     lib = P.emulation_library()
-    lp, Kv, flags, bv, src, eta = bench.make_slab_problem(4, 0, 1, layers=3 * world)
+    if strong:
+        lp, Kv, flags, bv, src, eta = bench.make_slab_problem(7, 0, 1, strong=True)
+    else:
+        lp, Kv, flags, bv, src, eta = bench.make_slab_problem(4, 0, 1, layers=3 * world)
     ctx = pa.Context(0, lib)
     ctx.set_grid(lp.raw)
     ctx.set_params(Kv, flags, None, eta)
