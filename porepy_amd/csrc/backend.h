@@ -146,6 +146,35 @@ inline void be_free(void* p) {
   if (tls_pool && tls_pool->give(p)) return;
   raw_free(p);
 }
+#ifndef PFV_EMULATE
+// Waiting for the stream: poll instead of sleeping on the completion interrupt.  A step has ~70
+// points where the host needs a number from the device (sizes of the next allocation, convergence);
+// with hipStreamSynchronize each costs a wake-up, which on a loaded host went from ~20 us to ~0.5 ms
+// (107 -> 178 ms per step on such a box).  PFV_SPIN_WAIT=0 goes back to blocking waits.
+inline bool spin_wait_enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("PFV_SPIN_WAIT");
+    return !(e && std::atoi(e) == 0);
+  }();
+  return on;
+}
+inline void wait_stream(stream_t s) {
+  if (!spin_wait_enabled()) {
+    PFV_HIP_CHECK(hipStreamSynchronize(s));
+    return;
+  }
+  for (;;) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) PFV_HIP_CHECK(e);
+  }
+}
+inline void* pinned_scratch() {  // 4 KB of page-locked host memory per thread: target of the small reads
+  thread_local void* p = nullptr;
+  if (!p) PFV_HIP_CHECK(hipHostMalloc(&p, 4096, hipHostMallocDefault));
+  return p;
+}
+#endif
 inline void be_h2d(void* dst, const void* src, size_t bytes, stream_t s) {
   if (!bytes) return;
 #ifdef PFV_EMULATE
@@ -153,7 +182,7 @@ inline void be_h2d(void* dst, const void* src, size_t bytes, stream_t s) {
   std::memcpy(dst, src, bytes);
 #else
   PFV_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
-  PFV_HIP_CHECK(hipStreamSynchronize(s));
+  wait_stream(s);
 #endif
 }
 inline void be_d2h(void* dst, const void* src, size_t bytes, stream_t s) {
@@ -162,8 +191,15 @@ inline void be_d2h(void* dst, const void* src, size_t bytes, stream_t s) {
   (void)s;
   std::memcpy(dst, src, bytes);
 #else
+  if (bytes <= 4096 && spin_wait_enabled()) {
+    void* p = pinned_scratch();
+    PFV_HIP_CHECK(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, s));
+    wait_stream(s);
+    std::memcpy(dst, p, bytes);
+    return;
+  }
   PFV_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
-  PFV_HIP_CHECK(hipStreamSynchronize(s));
+  wait_stream(s);
 #endif
 }
 inline void be_d2d(void* dst, const void* src, size_t bytes, stream_t s) {
@@ -188,7 +224,7 @@ inline void be_sync(stream_t s) {
 #ifdef PFV_EMULATE
   (void)s;
 #else
-  PFV_HIP_CHECK(hipStreamSynchronize(s));
+  wait_stream(s);
 #endif
 }
 
@@ -241,7 +277,15 @@ struct Timer {
   void start(stream_t s) { PFV_HIP_CHECK(hipEventRecord(a, s)); }
   double stop(stream_t s) {
     PFV_HIP_CHECK(hipEventRecord(b, s));
-    PFV_HIP_CHECK(hipEventSynchronize(b));
+    if (spin_wait_enabled()) {
+      for (;;) {
+        const hipError_t e = hipEventQuery(b);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) PFV_HIP_CHECK(e);
+      }
+    } else {
+      PFV_HIP_CHECK(hipEventSynchronize(b));
+    }
     float ms = 0.f;
     PFV_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     return ms;
