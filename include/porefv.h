@@ -290,6 +290,33 @@ pfv_status pfv_copy_device_vector(pfv_ctx* h, int which, double* d_dst, int64_t 
 pfv_status pfv_amg_setup(pfv_ctx* h, int64_t n_own);
 pfv_status pfv_amg_apply_device(pfv_ctx* h, const double* d_r, double* d_z);
 
+/* Sharded Krylov solve: the fused BiCGStab / CG loop of pfv_solve on the rows of the cells this rank
+ * owns (the leading n_own rows of the active system; owned cells are numbered first, the remaining
+ * columns are halo cells owned by other ranks), with the two data exchanges of the distributed
+ * method handed to the caller.  The reference has no distributed path; the split follows its
+ * sub-problem machinery (numerics/fv/_fvutils.py:414-539), the solve stands in for
+ * SolutionStrategy.solve_linear_system (models/solution_strategy.py:830-884).
+ *   exchange_halo(user, d_x, stream): entries [n_own, n_local) of the SpMV input d_x are to be
+ *     filled from their owners (RCCL ncclSend / ncclRecv over xGMI); the owned entries are current;
+ *   allreduce_sum(user, d_vals, count, stream): in-place sum over the ranks of count (<= 2) doubles
+ *     in device memory (ncclAllReduce) -- one call per fused pair of dot products.
+ * Both run on the calling thread between kernel launches and must only enqueue work ordered with
+ * `stream` (the handle's hipStream_t as void*, see pfv_set_stream); a non-zero return aborts the
+ * solve with PFV_ERR_ARGUMENT.  d_work: 2 * n_local + 2 doubles of caller device memory (the two
+ * SpMV inputs d_x the hooks see are d_work and d_work + n_local, d_vals is d_work + 2 * n_local).
+ * Preconditioner as selected by pfv_set_preconditioner: Jacobi, or one cycle of the block hierarchy
+ * of pfv_amg_setup(n_own) (block Jacobi across ranks, no communication inside).  Every rank takes
+ * the same branches: the convergence test reads the reduced residual.  d_x_owned receives n_own
+ * values (device memory, zero start). */
+typedef struct {
+  int (*exchange_halo)(void* user, double* d_x, void* stream);
+  int (*allreduce_sum)(void* user, double* d_vals, int count, void* stream);
+  void* user;
+} pfv_shard_hooks;
+pfv_status pfv_solve_sharded(pfv_ctx* h, int method, double rtol, int maxit, int64_t n_own,
+                             const pfv_shard_hooks* hooks, double* d_work, double* d_x_owned,
+                             pfv_solve_info* info);
+
 /* run this handle's work on an externally owned HIP stream (hipStream_t passed as void*, e.g.
  * torch.cuda.current_stream().cuda_stream) so that it is ordered with the caller's kernels and
  * RCCL collectives.  NULL is the legacy default stream (what torch's default stream is) -- the

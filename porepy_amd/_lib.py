@@ -37,7 +37,7 @@ EXPORTS = [
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
     "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
-    "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces",
+    "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces", "pfv_solve_sharded",
 ]
 
 
@@ -57,6 +57,15 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)            # (user, d_x, stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)  # (user, d_vals, count, stream)
+
+
+class ShardHooks(C.Structure):
+    """pfv_shard_hooks of include/porefv.h."""
+    _fields_ = [("exchange_halo", HALO_FN), ("allreduce_sum", ALLREDUCE_FN), ("user", C.c_void_p)]
 
 
 class PorefvError(RuntimeError):
@@ -154,6 +163,9 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_spmv_device_rows.restype = C.c_int
     lib.pfv_copy_device_vector.argtypes = [_h, C.c_int, C.c_void_p, C.c_int64]
     lib.pfv_copy_device_vector.restype = C.c_int
+    lib.pfv_solve_sharded.argtypes = [_h, C.c_int, C.c_double, C.c_int, C.c_int64, C.POINTER(ShardHooks),
+                                      C.c_void_p, C.c_void_p, C.POINTER(SolveInfo)]
+    lib.pfv_solve_sharded.restype = C.c_int
     lib.pfv_set_stream.argtypes = [_h, C.c_void_p]
     lib.pfv_set_stream.restype = C.c_int
     lib.pfv_mpsa_set_params.argtypes = [_h, _dp, _dp, _up, _up, C.c_double]
@@ -556,6 +568,45 @@ class Context:
     def amg_apply_device(self, r_ptr: int, z_ptr: int):
         """z = V-cycle(r) on device vectors (length of the block given to amg_setup)."""
         self._check(self.lib.pfv_amg_apply_device(self._h, C.c_void_p(r_ptr), C.c_void_p(z_ptr)))
+
+    def solve_sharded(self, n_own: int, exchange_halo, allreduce_sum, work_ptr: int, x_ptr: int,
+                      method="bicgstab", rtol=1e-10, maxit=20000, precond="jacobi", raise_on_fail=False):
+        """The fused Krylov loop on the leading ``n_own`` rows of the assembled system (pfv_solve_sharded).
+        ``exchange_halo(d_x_ptr)`` fills the halo entries of the SpMV input at that address,
+        ``allreduce_sum(d_vals_ptr, count)`` sums ``count`` doubles over the ranks in place; both only
+        enqueue work on the handle's stream.  ``work_ptr``: 2 n_local + 2 doubles of device memory (the
+        addresses the hooks see point into it), ``x_ptr``: n_own doubles for the solution."""
+        code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB}[method]
+        self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1}[precond]))
+        failure = []
+
+        def _halo(_user, d_x, _stream):
+            try:
+                exchange_halo(int(d_x))
+                return 0
+            except BaseException as e:  # must not propagate through the C frames
+                failure.append(e)
+                return 1
+
+        def _red(_user, d_vals, count, _stream):
+            try:
+                allreduce_sum(int(d_vals), int(count))
+                return 0
+            except BaseException as e:
+                failure.append(e)
+                return 1
+
+        hooks = ShardHooks(HALO_FN(_halo), ALLREDUCE_FN(_red), None)
+        info = SolveInfo()
+        st = self.lib.pfv_solve_sharded(self._h, code, float(rtol), int(maxit), int(n_own), C.byref(hooks),
+                                        C.c_void_p(work_ptr), C.c_void_p(x_ptr), C.byref(info))
+        if failure:
+            raise failure[0]
+        out = {"iterations": info.iterations, "converged": bool(info.converged),
+               "rel_residual": info.rel_residual, "solve_ms": info.solve_ms}
+        if st != 0 and (raise_on_fail or st != 6):
+            self._check(st)
+        return out
 
     def set_stream(self, stream_ptr: int | None):
         """Run on the caller's HIP stream (0 / None = the legacy default stream, torch's default)."""

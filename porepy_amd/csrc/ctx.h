@@ -199,6 +199,10 @@ struct pfv_ctx_impl {
   std::unique_ptr<Amg> amg_block;    // pfv_amg_setup: hierarchy of the leading block (sharded solves)
   CsrPattern pat_block;
   Buf<double> val_block;
+  // set only while pfv_solve_sharded runs: the caller's exchange hooks and work space
+  const pfv_shard_hooks* shard = nullptr;
+  double* shard_work = nullptr;      // [2 * shard_nloc + 2]: the two SpMV inputs (owned + halo entries), reduction scratch
+  int64_t shard_nloc = 0;
 
   pfv_stats stats{};
 

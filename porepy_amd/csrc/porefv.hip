@@ -1071,6 +1071,89 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
   return st;
 }
 
+namespace {
+// the leading rows of a pattern as a pattern of its own (shares the index arrays, frees nothing)
+struct RowsView {
+  pfv::CsrPattern V;
+  RowsView(const pfv::CsrPattern& P, int64_t nrows) {
+    V.nrows = nrows;
+    V.ncols = P.ncols;
+    V.nnz = P.nnz;  // (the window's entry positions index the full arrays)
+    V.max_row = P.max_row;
+    V.indptr.p = P.indptr.p;
+    V.indices.p = P.indices.p;
+  }
+  ~RowsView() {
+    V.indptr.p = nullptr;
+    V.indices.p = nullptr;
+  }
+};
+}  // namespace
+
+pfv_status pfv_solve_sharded(pfv_ctx* h, int method, double rtol, int maxit, int64_t n_own,
+                             const pfv_shard_hooks* hooks, double* d_work, double* d_x_owned,
+                             pfv_solve_info* info) {
+  pfv::SolveResult res;
+  pfv_status st = guarded(h, [&] {
+    require(h->active.valid, "assemble first");
+    require(hooks && hooks->exchange_halo && hooks->allreduce_sum, "both hooks are required");
+    require(d_work && d_x_owned, "work space and x are required");
+    require(method == PFV_SOLVE_CG || method == PFV_SOLVE_BICGSTAB, "a sharded solve runs PFV_SOLVE_CG or PFV_SOLVE_BICGSTAB");
+    require(rtol > 0 && maxit > 0, "rtol and maxit must be positive");
+    const int64_t n_loc = h->active.n;
+    require(n_own > 0 && n_own <= n_loc && n_own % h->active_bs == 0, "n_own out of range");
+    auto s = h->stream;
+    pfv::Timer tm;
+    tm.start(s);
+    const pfv::CsrPattern& P = *h->active.P;
+    RowsView rows(P, n_own);
+    pfv::LinSys sys = h->active;
+    sys.P = &rows.V;
+    sys.n = n_own;
+    sys.win = nullptr;
+    if (P.nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000)) {
+      if (h->win_rows_for != P.indices.p || h->win_rows_n != n_own) {
+        pfv::win_build(*h, rows.V, h->win_rows);
+        h->win_rows_for = P.indices.p;
+        h->win_rows_n = n_own;
+      }
+      if (h->win_rows.ok) sys.win = &h->win_rows;
+    }
+    pfv::Precond M;
+    const pfv::Precond* Mp = nullptr;
+    if (h->precond == PFV_PRECOND_AMG) {
+      require(h->amg_block && h->amg_block->valid && h->amg_block->lev[0]->n == n_own,
+              "pfv_amg_setup(n_own) first: the sharded solve preconditions with the hierarchy of the owned block");
+      M.amg = h->amg_block.get();
+      Mp = &M;
+    }
+    pfv::be_memset(d_x_owned, 0, sizeof(double) * (size_t)n_own, s);
+    pfv::be_memset(d_work, 0, sizeof(double) * (size_t)(2 * n_loc + 2), s);
+    h->shard = hooks;
+    h->shard_work = d_work;
+    h->shard_nloc = n_loc;
+    try {
+      res = pfv::krylov_solve(*h, sys, method, rtol, maxit, d_x_owned, true, Mp);
+    } catch (...) {
+      h->shard = nullptr;
+      throw;
+    }
+    h->shard = nullptr;
+    h->stats.solve_ms = tm.stop(s);
+  });
+  if (info) {
+    info->iterations = res.iterations;
+    info->converged = res.converged ? 1 : 0;
+    info->rel_residual = res.relres;
+    info->solve_ms = h ? h->stats.solve_ms : 0.0;
+  }
+  if (st == PFV_OK && !res.converged) {
+    h->err = "Krylov solver did not reach the requested tolerance";
+    return PFV_ERR_NOT_CONVERGED;
+  }
+  return st;
+}
+
 pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out) {
   return guarded(h, [&] {
     require(out != nullptr, "null output");

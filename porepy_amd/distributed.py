@@ -281,10 +281,20 @@ class ShardedMpfa:
         self.ctx.spmv_device_rows(self.system_matrix, self.n_own, x_full.data_ptr(), out_owned.data_ptr())
 
     def solve(self, method: str = "bicgstab", rtol: float = 1e-10, maxit: int = 20000, check_every: int = 10,
-              precond: str = "jacobi"):
+              precond: str = "jacobi", driver: str = "library"):
         """Returns (x_owned as a torch tensor, info).  precond = "amg": every rank applies one V-cycle of
         the aggregation AMG of its own diagonal block (owned cells x owned cells) -- block Jacobi
-        across ranks, no communication inside the preconditioner."""
+        across ranks, no communication inside the preconditioner.
+
+        driver = "library" (default): the fused Krylov loop of the C ABI (``pfv_solve_sharded``: windowed
+        SpMV with fused dot products, fused vector updates, scalars resident in HBM) calling back here
+        for the two exchanges of the distributed method -- the halo entries of each SpMV input
+        (point-to-point) and one all-reduce per fused pair of dot products.  driver = "torch": the same
+        iteration spelled out in torch ops around ``pfv_spmv_device_rows`` (kept as the cross-check)."""
+        if driver == "library":
+            return self._solve_library(method, rtol, maxit, precond)
+        if driver != "torch":
+            raise ValueError("driver must be 'library' or 'torch'")
         torch = self.torch
         n, dev = self.n_own, self.device
         self._use_torch_stream()
@@ -380,6 +390,43 @@ class ShardedMpfa:
                     break
                 if rr != rr:
                     break
+        return x, info
+
+    def _solve_library(self, method, rtol, maxit, precond):
+        torch = self.torch
+        n, nloc, dev = self.n_own, self.n_loc, self.device
+        if precond not in ("jacobi", "amg"):
+            raise ValueError("precond must be 'jacobi' or 'amg'")
+        self._use_torch_stream()
+        if precond == "amg" and not self._amg_ready:
+            self.ctx.amg_setup(n)
+            self._amg_ready = True
+        work = torch.empty(2 * nloc + 2, dtype=torch.float64, device=dev)
+        x = torch.empty(n, dtype=torch.float64, device=dev)
+        views = {work.data_ptr(): work[:nloc], work.data_ptr() + 8 * nloc: work[nloc:2 * nloc]}
+        red = work[2 * nloc:]
+        red_ptr = work.data_ptr() + 16 * nloc
+        multi = self.dist is not None and self.dist.get_world_size() > 1
+
+        def exchange_halo(ptr):
+            self.plan.exchange(views[ptr])
+
+        def allreduce_sum(ptr, count):
+            if ptr != red_ptr or count > 2:
+                raise RuntimeError("unexpected reduction buffer")
+            if multi:
+                # gloo cannot reduce device tensors in place on every build: stage through the host there
+                if red.is_cuda and self.dist.get_backend() == "gloo":
+                    h = red.cpu()
+                    self.dist.all_reduce(h)
+                    red.copy_(h)
+                else:
+                    self.dist.all_reduce(red)
+
+        info = self.ctx.solve_sharded(n, exchange_halo, allreduce_sum, work.data_ptr(), x.data_ptr(),
+                                      method=method, rtol=rtol, maxit=maxit, precond=precond)
+        info["halo_bytes_per_exchange"] = self.plan.bytes_per_exchange
+        info["driver"] = "library"
         return x, info
 
     def owned_system_rows(self):

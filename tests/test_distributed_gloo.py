@@ -66,8 +66,11 @@ def _worker(rank, world, port, kind, method, out, precond="jacobi"):
         sh.assemble(bv[lp.face_gid], src[lp.cell_gid])
         A_own, b_own = sh.owned_system_rows()
         x, info = sh.solve(method=method, rtol=1e-12, maxit=3000, check_every=1, precond=precond)
+        assert info["driver"] == "library"  # the fused loop of the C ABI with the two exchange hooks
+        # the same iteration spelled out in torch ops: same method, same exchanges
+        xt, info_t = sh.solve(method=method, rtol=1e-12, maxit=3000, check_every=1, precond=precond, driver="torch")
         torch.save({"gid": lp.cell_gid, "n_own": lp.n_own, "A": A_own, "b": b_own, "x": x.numpy(),
-                    "info": info}, os.path.join(out, f"r{rank}.pt"))
+                    "info": info, "x_torch": xt.numpy(), "info_torch": info_t}, os.path.join(out, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -108,6 +111,9 @@ def test_two_rank_sharded_assembly_and_solve(tmp_path, kind, method, precond):
         assert np.allclose(o["b"], (b + src)[own], rtol=1e-12, atol=1e-14)
         assert o["info"]["converged"]
         assert np.linalg.norm(o["x"] - x_ref[own]) <= 1e-9 * np.linalg.norm(x_ref)
+        assert o["info_torch"]["converged"]
+        assert np.linalg.norm(o["x_torch"] - x_ref[own]) <= 1e-9 * np.linalg.norm(x_ref)
+        assert abs(o["info"]["iterations"] - o["info_torch"]["iterations"]) <= 3
     assert seen.all()
 
 

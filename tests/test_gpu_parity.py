@@ -224,8 +224,8 @@ def test_windowed_spmv_paths(lib, monkeypatch):
 
 
 def test_sharded_driver_single_rank_with_block_amg(lib):
-    """The multi-GPU driver on one rank (no exchange): device-pointer SpMV, block-AMG V-cycles on torch
-    tensors, against the single-context solve."""
+    """The multi-GPU driver on one rank (hooks called, nothing to exchange): the fused sharded Krylov
+    loop of the C ABI with block-AMG V-cycles, against its Jacobi run and the torch-op driver."""
     import torch
 
     from porepy_amd import distributed as D
@@ -246,9 +246,13 @@ def test_sharded_driver_single_rank_with_block_amg(lib):
     sh.assemble(bv[lp.face_gid], g.cell_volumes[lp.cell_gid])
     xj, ij = sh.solve("bicgstab", rtol=1e-12, check_every=1)
     xa, ia = sh.solve("bicgstab", rtol=1e-12, precond="amg")
+    assert ij["driver"] == ia["driver"] == "library"  # pfv_solve_sharded with the exchange hooks
     assert ia["converged"] and ia["iterations"] * 4 < ij["iterations"]
-    xa, xj = xa.cpu().numpy(), xj.cpu().numpy()
+    xt, it = sh.solve("bicgstab", rtol=1e-12, precond="amg", driver="torch")  # the torch-op spelling
+    assert it["converged"] and abs(it["iterations"] - ia["iterations"]) <= 3
+    xa, xj, xt = xa.cpu().numpy(), xj.cpu().numpy(), xt.cpu().numpy()
     assert np.linalg.norm(xa - xj) <= 1e-9 * np.linalg.norm(xj)
+    assert np.linalg.norm(xt - xa) <= 1e-9 * np.linalg.norm(xj)
     torch.cuda.synchronize()
 
 
