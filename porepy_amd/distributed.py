@@ -255,12 +255,24 @@ class ShardedMpfa:
         self.ctx.discretize(rebuild_topology=rebuild_topology, skip_vector_source=skip_vector_source)
 
     def assemble(self, bc_values_local, source_local=None):
-        self.ctx.assemble(bc_values_local, None, source_local)
-        self._fetch_system()
+        """bc values / sources of the local grid: numpy arrays, or torch tensors resident on this
+        rank's device (no PCIe traffic in the step)."""
+        torch = self.torch
+        if isinstance(bc_values_local, torch.Tensor):
+            self._use_torch_stream()
+            self.ctx.assemble_device(bc_values_local.data_ptr(), 0,
+                                     0 if source_local is None else source_local.data_ptr())
+        else:
+            self.ctx.assemble(bc_values_local, None, source_local)
+        self._system_changed()
+
+    def _system_changed(self):
+        self._amg_ready = False  # the matrix may have changed
+        self._b = self._diag = None
 
     def _fetch_system(self):
+        """rhs and diagonal as torch tensors (only the torch driver needs them)."""
         torch = self.torch
-        self._amg_ready = False  # the matrix may have changed
         self._b = torch.empty(self.n_loc, dtype=torch.float64, device=self.device)
         self._diag = torch.empty(self.n_loc, dtype=torch.float64, device=self.device)
         self._use_torch_stream()
@@ -298,6 +310,8 @@ class ShardedMpfa:
         torch = self.torch
         n, dev = self.n_own, self.device
         self._use_torch_stream()
+        if self._b is None:
+            self._fetch_system()
         b = self._b[:n]
         dinv = 1.0 / self._diag[:n]
         f64 = dict(dtype=torch.float64, device=dev)
@@ -462,4 +476,4 @@ class ShardedMpsa(ShardedMpfa):
 
     def assemble(self, bc_values_local, source_local=None):
         self.ctx.mpsa_assemble(bc_values_local, source_local)
-        self._fetch_system()
+        self._system_changed()

@@ -223,6 +223,21 @@ def test_windowed_spmv_paths(lib, monkeypatch):
     assert abs(sols[0]["bicgstab"] - sols[1]["bicgstab"]) <= 2, sols
 
 
+@pytest.mark.parametrize("k", ["4", "8"])
+def test_amg_candidate_lists(lib, monkeypatch, k):
+    """PFV_AMG_CAND: the handshake rounds of the aggregation choose among the K strongest neighbours of
+    a row (one pass over the matrix per pairwise pass), the last rounds among all neighbours of the rows
+    still free: same quality of the hierarchy as re-reading every row in every round."""
+    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([10, 10, 10], [1, 1, 1])), 0.02)
+    monkeypatch.setenv("PFV_AMG_CAND", "0")
+    base, _, _ = P.amg_preconditioner(lib, g)
+    monkeypatch.setenv("PFV_AMG_CAND", k)
+    out, _, _ = P.amg_preconditioner(lib, g)
+    assert out["bicgstab"] <= base["bicgstab"] + 3, (out, base)
+    g = _geo(pa.CartGrid([14, 14, 14], [1, 1, 1]))
+    P.amg_preconditioner(lib, g, hetero_sigma=2.0)
+
+
 def test_sharded_driver_single_rank_with_block_amg(lib):
     """The multi-GPU driver on one rank (hooks called, nothing to exchange): the fused sharded Krylov
     loop of the C ABI with block-AMG V-cycles, against its Jacobi run and the torch-op driver."""
