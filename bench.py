@@ -362,6 +362,29 @@ def main():
             sh.assemble(d_bv, d_src)
             return sh.solve("bicgstab", rtol=args.rtol, maxit=20000, precond=args.precond, driver=drv)
 
+    # Untimed pre-warm, before (and not counted among) the W warmup steps: the first process on a fresh box
+    # has been seen running its launch-bound phases at half speed for its first seconds (busy host, cold
+    # caches); repeat the step until two consecutive step times agree.  Every rank takes the same
+    # decision (the sharded step contains collectives).
+    prewarm = 0
+    if os.environ.get("PFV_BENCH_PREWARM", "1") != "0":
+        last = None
+        for _ in range(6):
+            barrier()
+            tp = time.perf_counter()
+            step()
+            ctx.sync()
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - tp
+            prewarm += 1
+            stable = 1 if (last is not None and abs(dtp - last) <= 0.05 * last) else 0
+            if dist is not None:
+                tst = torch.tensor([stable], dtype=torch.int32, device="cuda")
+                dist.all_reduce(tst, op=dist.ReduceOp.MIN)
+                stable = int(tst.item())
+            last = dtp
+            if stable:
+                break
     for _ in range(args.warmup):
         x, info = step()
     barrier()
@@ -434,12 +457,15 @@ def main():
     out_bytes = 8.0 * sum(nnz.values()) + 4.0 * (nnz["flux"] + nnz["bound_flux"] + nnz["vs"]) + 12.0 * nnzA
     nfl, nnl = lp.raw["face_centers"].shape[1], lp.raw["nodes"].shape[1]
     in_bytes = 8.0 * (3 * nnl + 3 * nloc + 7 * nfl) + 72.0 * nloc + 5.0 * 4 * nloc + 4.0 * 3 * nfl
-    asm_ms = st["topology_ms"] + st["symbolic_ms"] + st["node_ms"] + st["face_ms"] + st["assemble_ms"]
+    # the interaction-region kernel runs beside the symbolic phase (second stream): the phases overlap, the
+    # assembly time is the span of the discretize call plus div@flux / rhs
+    asm_ms = st["discretize_ms"] + st["assemble_ms"]
     assembly = {"algorithmic_bytes": out_bytes + in_bytes, "ms": asm_ms,
                 "achieved_GBs": (out_bytes + in_bytes) / (asm_ms * 1e-3) / 1e9,
                 "frac_of_hbm_peak": (out_bytes + in_bytes) / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "phases_ms": {k: st[k] for k in ("topology_ms", "symbolic_ms", "node_ms", "face_ms",
-                                                 "assemble_ms", "solve_ms")},
+                                                 "assemble_ms", "solve_ms", "discretize_ms")},
+                "phases_note": "symbolic_ms and node_ms are overlapping spans (two streams); discretize_ms is the whole call",
                 "cells_per_s_assembly_only": nloc / (asm_ms * 1e-3)}
 
     # the assembly kernel with the most time: the face kernel (gathers the per-node tables, writes the
@@ -488,7 +514,7 @@ def main():
             "metric": "cells/sec MPFA assemble+solve, 3D unstructured grid",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "prewarm_steps_untimed": prewarm,
             "config": {"workload": f"BASELINE configs[2] (the 2 M-cell grid the north_star target is quoted on): "
                                    f"3D simplex box, {nc} owned tetrahedra per GPU (n_side={args.n_side}), perturbed "
                                    "nodes, full-tensor anisotropic heterogeneous K, Dirichlet x-faces; "

@@ -99,6 +99,9 @@ typedef struct {
   double amg_setup_ms;            /* last AMG hierarchy build */
   double amg_operator_complexity; /* sum of nnz over the levels / nnz of the system */
   int64_t amg_levels, amg_coarsest_rows;
+  double discretize_ms;           /* whole pfv_mpfa_discretize call; less than the sum of its phases when the
+                                     interaction-region kernel ran beside the symbolic phase on the handle's
+                                     second stream (symbolic_ms and node_ms then are overlapping spans) */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);

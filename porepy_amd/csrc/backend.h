@@ -290,8 +290,44 @@ struct Timer {
     PFV_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     return ms;
   }
+  // two-step form for work on a second stream: mark() records the end without waiting,
+  // elapsed_after_sync() is read once the host has to wait for that work anyway
+  void mark(stream_t s) { PFV_HIP_CHECK(hipEventRecord(b, s)); }
+  double elapsed_after_sync() {
+    PFV_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0.f;
+    PFV_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+  }
 #endif
 };
+
+#ifndef PFV_EMULATE
+// fork / join of two streams with events: `side` first waits for everything enqueued on `main` so
+// far; join() makes `main` wait for everything enqueued on `side` since
+struct StreamFork {
+  stream_t main, side;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool joined = false;
+  StreamFork(stream_t m, stream_t sd) : main(m), side(sd) {
+    PFV_HIP_CHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    PFV_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    PFV_HIP_CHECK(hipEventRecord(e0, main));
+    PFV_HIP_CHECK(hipStreamWaitEvent(side, e0, 0));
+  }
+  void join() {
+    PFV_HIP_CHECK(hipEventRecord(e1, side));
+    PFV_HIP_CHECK(hipStreamWaitEvent(main, e1, 0));
+    joined = true;
+  }
+  ~StreamFork() {
+    if (!joined) (void)hipStreamSynchronize(side);  // error path: nothing may outlive the caller's buffers
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+  StreamFork(const StreamFork&) = delete;
+};
+#endif
 
 // ---------------------------------------------------------------- launches
 struct WaveCtx {
@@ -583,6 +619,35 @@ PFV_HD inline void atomic_min_i32(int* addr, int v) {
   atomicMin(addr, v);
 #else
   (void)addr; (void)v;
+#endif
+#endif
+}
+// compare-and-swap / exchange on a 32-bit word (LDS hash tables); both return the old value
+PFV_HD inline int atomic_cas_i32(int* addr, int expected, int desired) {
+#ifdef PFV_EMULATE
+  const int old = *addr;
+  if (old == expected) *addr = desired;
+  return old;
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicCAS(addr, expected, desired);
+#else
+  (void)addr; (void)expected; (void)desired;
+  return 0;
+#endif
+#endif
+}
+PFV_HD inline int atomic_exch_i32(int* addr, int v) {
+#ifdef PFV_EMULATE
+  const int old = *addr;
+  *addr = v;
+  return old;
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicExch(addr, v);
+#else
+  (void)addr; (void)v;
+  return 0;
 #endif
 #endif
 }

@@ -63,6 +63,8 @@ struct pfv_ctx_impl {
   int device = 0;
   stream_t stream{};      // stream all work of this handle is issued on
   stream_t own_stream{};  // the stream created with the handle (stream may point elsewhere, pfv_set_stream)
+  stream_t aux_stream{};  // second stream of the handle: the interaction-region kernel runs there while the
+                          // symbolic phase runs on `stream` (both only need the sub-cell topology)
   std::string err;
   Scratch scratch;
 
@@ -187,6 +189,7 @@ struct pfv_ctx_impl {
   // centres (reorder.inc): the numbering of the grid generator decides how local the SpMV gathers are.
   bool active_is_grid = false;       // active rows = cells (x active_bs) in the grid's numbering
   bool have_cell_order = false;
+  bool cell_order_identity = false;  // the grid's own numbering already follows the curve: solve in place
   Buf<int32_t> cell_perm, cell_iperm;  // new position -> cell, cell -> new position
   CsrPattern pat_perm;
   Buf<double> val_perm, diag_perm, rhs_perm, x_perm;

@@ -87,6 +87,7 @@ pfv_status pfv_create(int device, pfv_ctx** out) {
     PFV_HIP_CHECK(hipSetDevice(device));
     PFV_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = h->stream;
+    PFV_HIP_CHECK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
 #endif
   } catch (...) {
     delete h;
@@ -103,12 +104,14 @@ void pfv_destroy(pfv_ctx* h) {
   if (h->stream) {
     (void)hipStreamSynchronize(h->stream);
   }
-  hipStream_t s = h->own_stream;
+  hipStream_t s = h->own_stream, s2 = h->aux_stream;
+  if (s2) (void)hipStreamSynchronize(s2);
   {
     pfv::PoolScope pool_scope(&h->pool);
     delete h;
   }
   if (s) (void)hipStreamDestroy(s);
+  if (s2) (void)hipStreamDestroy(s2);
 #else
   {
     pfv::PoolScope pool_scope(&h->pool);
@@ -253,20 +256,47 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
     require(h->have_grid && h->have_params, "grid and parameters must be set before discretize");
     require(h->nd >= 2, "MPFA needs a 2-D or 3-D grid (1-D: pfv_tpfa_discretize)");
     auto s = h->stream;
-    pfv::Timer tm;
+    pfv::Timer tm, tall;
+    tall.start(s);
+    bool node_done = false;
     if (!h->have_topology || !h->have_symbolic || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
       tm.start(s);
       pfv::build_topology(*h);
       h->stats.topology_ms = tm.stop(s);
-      tm.start(s);
-      pfv::build_symbolic(*h);
-      h->stats.symbolic_ms = tm.stop(s);
+#ifndef PFV_EMULATE
+      // The symbolic phase (CSR patterns) and the interaction-region kernel (local inverses) both
+      // depend on the sub-cell topology only, and both are bound by latency at low occupancy, not by
+      // bandwidth: the node kernel goes to the handle's second stream and shares the CUs with the
+      // symbolic kernels.  Its buffers live in the handle (nothing it touches passes through the block
+      // cache while the other stream runs); the status words of the two phases are disjoint.
+      if (h->aux_stream && pfv::env_int("PFV_OVERLAP_NODE", 1) != 0) {
+        pfv::StreamFork fork(s, h->aux_stream);   // aux waits for everything enqueued on s so far
+        pfv::Timer tn;
+        tn.start(h->aux_stream);
+        pfv::launch_node_kernel(*h, nullptr, h->aux_stream);
+        tn.mark(h->aux_stream);
+        tm.start(s);
+        pfv::build_symbolic(*h);
+        h->stats.symbolic_ms = tm.stop(s);
+        fork.join();                              // s waits for the node kernel
+        h->stats.node_ms = tn.elapsed_after_sync();
+        pfv::check_node_status(*h, s);
+        node_done = true;
+      }
+#endif
+      if (!node_done) {
+        tm.start(s);
+        pfv::build_symbolic(*h);
+        h->stats.symbolic_ms = tm.stop(s);
+      }
       h->tpfa_mode = false;
       h->have_sub_symbolic = false;
     }
-    tm.start(s);
-    pfv::run_node_kernel(*h);
-    h->stats.node_ms = tm.stop(s);
+    if (!node_done) {
+      tm.start(s);
+      pfv::run_node_kernel(*h);
+      h->stats.node_ms = tm.stop(s);
+    }
     const bool with_vs = !(flags & PFV_DISCR_SKIP_VECTOR_SOURCE);
     tm.start(s);
     if (h->subface_bc) {
@@ -277,6 +307,7 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
       pfv::run_face_kernel(*h, with_vs);
     }
     h->stats.face_ms = tm.stop(s);
+    h->stats.discretize_ms = tall.stop(s);
     h->have_numeric = true;
     h->rows_complete = !h->subface_bc;
     h->have_system = false;
@@ -989,6 +1020,9 @@ static pfv::LinSys solver_system(pfv_ctx* h, bool& permuted) {
   if (h->active_is_grid && sys.n == h->nc * bs && pfv::env_int("PFV_REORDER", 1) != 0 &&
       h->nc >= pfv::env_int("PFV_REORDER_MIN_CELLS", 256)) {
     if (!h->have_cell_order) pfv::build_cell_order(*h);
+  }
+  if (h->active_is_grid && h->have_cell_order && !h->cell_order_identity && sys.n == h->nc * bs &&
+      pfv::env_int("PFV_REORDER", 1) != 0 && h->nc >= pfv::env_int("PFV_REORDER_MIN_CELLS", 256)) {
     if (h->perm_for_val != sys.val) {
       pfv::permute_matrix(*h, sys, bs);
       h->perm_for_val = sys.val;

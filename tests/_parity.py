@@ -902,3 +902,43 @@ def full_size_patch_parity_mpsa(lib, n_side: int = 44, seeds=(0, None, -1)):
             assert rel_max_err(Gl, ora[name][ex(lfaces)]) < TOL, (name, seed)
         checked += lfaces.size
     return {"iterations": info["iterations"], "rows_checked": checked}
+
+
+def morton_numbered_grid_solve(lib, n=8):
+    """A grid whose cells are already numbered along the Morton curve of their centres is solved in place
+    (no renumbered copy of the system, reorder.inc); any other numbering goes through the copy.  Both
+    must give the solution of the direct solver."""
+    from porepy_amd import distributed as D
+
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.02)
+    rng = np.random.default_rng(3)
+    sc = np.exp(0.5 * rng.standard_normal(g.num_cells))
+    K = pa.SecondOrderTensor(kxx=sc, kyy=4 * sc, kzz=0.3 * sc, kxy=0.3 * sc)
+    raw0 = pa.grid_to_raw(g)
+    bf = g.get_all_boundary_faces()
+    dirf = bf[(g.face_centers[0, bf] < 1e-9) | (g.face_centers[0, bf] > 1 - 1e-9)]
+    flags = np.zeros(g.num_faces, dtype=np.uint8)
+    flags[bf] = 2
+    flags[dirf] = 1
+    bv = np.zeros(g.num_faces)
+    bv[dirf] = g.face_centers[0, dirf]
+    its = {}
+    for name in ("generator", "morton"):
+        order = np.arange(g.num_cells) if name == "generator" else D.morton_order(raw0["cell_centers"], 3)
+        raw = D.permute_cells(raw0, order)
+        ctx = pa.Context(0, lib)
+        ctx.set_grid(raw)
+        ctx.set_params(np.ascontiguousarray(K.values[:, :, order]), flags, None, 1.0 / 3.0)
+        ctx.discretize(skip_vector_source=True)
+        src = raw["cell_volumes"]
+        ctx.assemble(bv, None, src)
+        A, b = ctx.matrix(pa._lib.MAT_SYSTEM), ctx.rhs()
+        xo = spla.spsolve(A.tocsc(), b)
+        for precond in ("jacobi", "amg"):
+            x, info = ctx.solve("bicgstab", rtol=1e-12, maxit=5000, precond=precond)
+            assert info["converged"], (name, precond)
+            assert np.linalg.norm(x - xo) <= TOL * np.linalg.norm(xo), (name, precond)
+            its[name, precond] = info["iterations"]
+    return its

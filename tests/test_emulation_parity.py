@@ -160,6 +160,11 @@ def test_gmres(lib, restart):
     P.gmres_matches_direct(lib, g, restart=restart)
 
 
+def test_solve_in_place_on_morton_numbered_grid(lib):
+    its = P.morton_numbered_grid_solve(lib)
+    assert its["morton", "amg"] * 3 < its["morton", "jacobi"]
+
+
 def test_solver_for_assembled_csr_systems(lib):
     """pfv_set_system: any CSR system with a non-zero diagonal (rows not sorted, no grid)."""
     import scipy.sparse as sps
@@ -201,21 +206,6 @@ def test_amg_preconditioner(lib):
     P.amg_preconditioner(lib, g, hetero_sigma=2.0)
     g = _geo(pa.CartGrid([40, 30], [1, 1]))
     P.amg_preconditioner(lib, g)
-
-
-@pytest.mark.parametrize("k", ["4", "8"])
-def test_amg_candidate_lists(lib, monkeypatch, k):
-    """PFV_AMG_CAND: the handshake rounds of the aggregation choose among the K strongest neighbours of
-    a row (one pass over the matrix per pairwise pass), the last rounds among all neighbours of the rows
-    still free: same quality of the hierarchy as re-reading every row in every round."""
-    g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([10, 10, 10], [1, 1, 1])), 0.02)
-    monkeypatch.setenv("PFV_AMG_CAND", "0")
-    base, _, _ = P.amg_preconditioner(lib, g)
-    monkeypatch.setenv("PFV_AMG_CAND", k)
-    out, _, _ = P.amg_preconditioner(lib, g)
-    assert out["bicgstab"] <= base["bicgstab"] + 3, (out, base)
-    g = _geo(pa.CartGrid([14, 14, 14], [1, 1, 1]))
-    P.amg_preconditioner(lib, g, hetero_sigma=2.0)
 
 
 def test_amg_on_assembled_csr_and_symmetric_cg(lib):
