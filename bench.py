@@ -205,8 +205,9 @@ def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = N
     owned = (ckg >= lo_k) & (ckg < hi_k)
     # local numbering: owned cells first, each group along a Morton curve (locality of the SpMV gathers)
     io, ih = np.flatnonzero(owned), np.flatnonzero(~owned)
-    io = io[D.morton_order(raw["cell_centers"][:, io], 3)]
-    ih = ih[D.morton_order(raw["cell_centers"][:, ih], 3)]
+    box = (raw["face_centers"].min(axis=1), raw["face_centers"].max(axis=1))  # the library's quantisation box
+    io = io[D.morton_order(raw["cell_centers"][:, io], 3, box)]
+    ih = ih[D.morton_order(raw["cell_centers"][:, ih], 3, box)]
     order = np.concatenate([io, ih])
     raw = D.permute_cells(raw, order)
     cgid, ckg = cgid[order], ckg[order]
@@ -523,6 +524,7 @@ def main():
                        "amg": ({"levels": st["amg_levels"], "operator_complexity": st["amg_operator_complexity"],
                                 "setup_ms": st["amg_setup_ms"], "coarsest_rows": st["amg_coarsest_rows"]}
                                if args.precond == "amg" else None),
+                       "solve_on_renumbered_copy": bool(st.get("solve_renumbered", 0)),
                        "iterations": info["iterations"], "converged": info["converged"],
                        "true_rel_residual": res_true,
                        "global_cells": ncells_total,

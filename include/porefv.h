@@ -102,6 +102,8 @@ typedef struct {
   double discretize_ms;           /* whole pfv_mpfa_discretize call; less than the sum of its phases when the
                                      interaction-region kernel ran beside the symbolic phase on the handle's
                                      second stream (symbolic_ms and node_ms then are overlapping spans) */
+  int64_t solve_renumbered;       /* 1: the last pfv_solve worked on the copy renumbered along the Morton curve,
+                                     0: in place (grid already numbered that way, or a user system) */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);

@@ -53,7 +53,7 @@ class Stats(C.Structure):
                 ("num_sub_half_faces", C.c_int64), ("sum_block_sq", C.c_int64),
                 ("max_block", C.c_int64), ("amg_setup_ms", C.c_double),
                 ("amg_operator_complexity", C.c_double), ("amg_levels", C.c_int64),
-                ("amg_coarsest_rows", C.c_int64), ("discretize_ms", C.c_double)]
+                ("amg_coarsest_rows", C.c_int64), ("discretize_ms", C.c_double), ("solve_renumbered", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -49,16 +49,26 @@ def partition_slabs(cell_centers: np.ndarray, nparts: int, axis: int = 2) -> np.
     return owner
 
 
-def morton_order(centers: np.ndarray, dim: int) -> np.ndarray:
+def morton_order(centers: np.ndarray, dim: int, box=None) -> np.ndarray:
     """Indices that sort points along a Morton curve (10 bits per axis).  The local numbering of a rank
     is free; a space-filling curve keeps the x gathers of the SpMV / AMG kernels local (the grid
-    generator's numbering - the six tetrahedra of a lattice cell ncells/6 apart - does not)."""
+    generator's numbering - the six tetrahedra of a lattice cell ncells/6 apart - does not).
+
+    ``box = (lo, hi)``: quantise against this box instead of the points' own; with the bounding box of
+    the grid's face centres the keys are the ones the library computes (csrc/reorder.inc), so a grid
+    numbered this way is recognised there and solved in place, without a renumbered copy of the system."""
     x = np.asarray(centers, dtype=float)[:dim]
     if x.shape[1] == 0:
         return np.zeros(0, dtype=np.int64)
-    lo = x.min(axis=1, keepdims=True)
-    ext = np.maximum(x.max(axis=1, keepdims=True) - lo, 1e-300)
-    q = np.minimum((x - lo) / ext * 1024.0, 1023.0).astype(np.int64)
+    if box is None:
+        lo = x.min(axis=1, keepdims=True)
+        ext = np.maximum(x.max(axis=1, keepdims=True) - lo, 1e-300)
+        q = np.minimum((x - lo) / ext * 1024.0, 1023.0).astype(np.int64)
+    else:
+        lo = np.asarray(box[0], dtype=float)[:dim, None]
+        ext = np.asarray(box[1], dtype=float)[:dim, None] - lo
+        sc = np.where(ext > 0, 1024.0 / np.where(ext > 0, ext, 1.0), 0.0)
+        q = np.clip((x - lo) * sc, 0.0, 1023.0).astype(np.int64)
     key = np.zeros(x.shape[1], dtype=np.int64)
     for b in range(10):
         for a in range(dim):

@@ -926,7 +926,8 @@ def morton_numbered_grid_solve(lib, n=8):
     bv[dirf] = g.face_centers[0, dirf]
     its = {}
     for name in ("generator", "morton"):
-        order = np.arange(g.num_cells) if name == "generator" else D.morton_order(raw0["cell_centers"], 3)
+        box = (raw0["face_centers"].min(axis=1), raw0["face_centers"].max(axis=1))
+        order = np.arange(g.num_cells) if name == "generator" else D.morton_order(raw0["cell_centers"], 3, box)
         raw = D.permute_cells(raw0, order)
         ctx = pa.Context(0, lib)
         ctx.set_grid(raw)
@@ -941,4 +942,5 @@ def morton_numbered_grid_solve(lib, n=8):
             assert info["converged"], (name, precond)
             assert np.linalg.norm(x - xo) <= TOL * np.linalg.norm(xo), (name, precond)
             its[name, precond] = info["iterations"]
+            assert ctx.stats()["solve_renumbered"] == (1 if name == "generator" else 0), name
     return its
