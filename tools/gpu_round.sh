@@ -1,6 +1,6 @@
 #!/bin/bash
-# One gpurun call: GPU parity suite, bench lines (default / sharded drivers / AMG candidate lists /
-# two ranks sharing the GPU over gloo) and a kernel trace.  Most important first: the call may be cut.
+# One gpurun call: GPU parity suite, bench lines (default / sharded drivers / two ranks sharing the GPU
+# over gloo) and a kernel trace.  Most important first: the call may be cut.
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out
@@ -15,8 +15,6 @@ timeout 330 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 stamp bench_default
 timeout 200 python bench.py --force-sharded --no-cpu-baseline --no-extra-configs > $O/bench_sharded_library.json 2> $O/bench_sharded_library.err
 stamp bench_sharded_library
-PFV_AMG_CAND=4 timeout 200 python bench.py --no-cpu-baseline --no-extra-configs --phases > $O/bench_cand4.json 2> $O/bench_cand4.err
-stamp bench_cand4
 PFV_BENCH_SHARE_GPU=1 timeout 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
   --master-port 29517 bench.py --gpus 2 --n-side 40 --no-cpu-baseline --no-extra-configs > $O/bench_2rank_shared_gpu.json 2> $O/bench_2rank_shared_gpu.err
 stamp bench_2rank
@@ -24,8 +22,6 @@ stamp bench_2rank
 stamp rocprof
 for db in $(find $O/prof -name '*.db' | head -1); do python profiles/summarize_rocpd.py $db > $O/kernel_stats.txt 2>> $O/rocprof.err; done
 find $O/prof -name '*.db' -size +40M -delete
-PFV_AMG_CAND=8 timeout 200 python bench.py --no-cpu-baseline --no-extra-configs > $O/bench_cand8.json 2> $O/bench_cand8.err
-stamp bench_cand8
 PFV_SHARDED_DRIVER=torch timeout 200 python bench.py --force-sharded --no-cpu-baseline --no-extra-configs > $O/bench_sharded_torch.json 2> $O/bench_sharded_torch.err
 stamp bench_sharded_torch
 tail -3 $O/pytest_gpu.log
