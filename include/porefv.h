@@ -149,6 +149,21 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags);
  * vector_source_dim = ``ambient_dimension`` (number of vector-source components per cell). */
 pfv_status pfv_tpfa_discretize(pfv_ctx* h, int vector_source_dim);
 
+/* Differentiable two-point transmissibilities: the numerical core of
+ * AdTpfaFlux.__transmissibility_matrix (models/constitutive_laws.py:1504-1578) on the half-face
+ * geometry of DifferentiableTpfa (numerics/fv/tpfa.py:546-620), value and derivative in one pass
+ * instead of two sparse products through the forward-AD machinery.  For every half-face
+ * e = (cell c, face f, sign), in the order of the cell_faces entries given to pfv_set_grid (cell by
+ * cell; the reference numbers its half-faces face by face, sps.find(sd.cell_faces), which only matters
+ * for vectors indexed by half-face - the Jacobian below is the same matrix either way):
+ *     t_e = d^T K_c n_f / |d|^2,  d = x_f - x_c        t_f = 1 / sum_{e of f} sgn_e / t_e
+ *     t_face[f] = t_f                                   (Nf values)
+ *     dt_dk[9 e + 3 r + s] = d t_f / d K_c[r][s] = t_f^2 sgn_e d_r n_s / (t_e^2 |d|^2)   (9 nnz(cell_faces))
+ * i.e. row f(e), column 9 c(e) + 3 r + s of the Jacobian of t_f_full with respect to the reference's
+ * k_c vector.  perm_33n: (3,3,Nc) C-order as in pfv_mpfa_set_params; needs only the grid.  The three
+ * arrays follow pfv_set_vectors_on_device (host by default). */
+pfv_status pfv_tpfa_transmissibility_ad(pfv_ctx* h, const double* perm_33n, double* t_face, double* dt_dk);
+
 /* Partial (re)discretization: the node-list launch behind ``specified_cells / _faces /
  * _nodes`` (numerics/fv/mpfa.py:178-204, 466-508) and ``update_discretization``
  * (mpfa.py:510-590, _fvutils.py:1090-1257).  ``faces`` = the faces whose rows are to be

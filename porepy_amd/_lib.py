@@ -37,7 +37,7 @@ EXPORTS = [
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
     "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
-    "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces", "pfv_solve_sharded",
+    "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces", "pfv_solve_sharded", "pfv_tpfa_transmissibility_ad",
 ]
 
 
@@ -163,6 +163,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_spmv_device_rows.restype = C.c_int
     lib.pfv_copy_device_vector.argtypes = [_h, C.c_int, C.c_void_p, C.c_int64]
     lib.pfv_copy_device_vector.restype = C.c_int
+    lib.pfv_tpfa_transmissibility_ad.argtypes = [_h, _dp, _dp, _dp]
+    lib.pfv_tpfa_transmissibility_ad.restype = C.c_int
     lib.pfv_solve_sharded.argtypes = [_h, C.c_int, C.c_double, C.c_int, C.c_int64, C.POINTER(ShardHooks),
                                       C.c_void_p, C.c_void_p, C.POINTER(SolveInfo)]
     lib.pfv_solve_sharded.restype = C.c_int
@@ -264,6 +266,7 @@ class Context:
             _ptr(fnp, _ip), _ptr(fni, _ip), _ptr(fn_, _dp), _ptr(fc, _dp), _ptr(cc, _dp), _ptr(fa, _dp)))
         self.nd, self.nc, self.nf, self.nn = nd, nc, nf, nn
         self.nsf = int(fnp[-1])
+        self.ncf = int(cfp[-1])
 
     def set_params(self, perm, bc_flags, robin_weight=None, eta=0.0, eta_subface=None):
         perm = _f64(perm)
@@ -607,6 +610,18 @@ class Context:
         if st != 0 and (raise_on_fail or st != 6):
             self._check(st)
         return out
+
+    def tpfa_transmissibility_ad(self, perm):
+        """Two-point face transmissibilities and their derivatives with respect to the permeability entries
+        of the neighbouring cells (include/porefv.h: pfv_tpfa_transmissibility_ad).  Returns
+        (t_face (Nf,), dt_dk (nnz(cell_faces), 9)) in the order of the cell_faces entries."""
+        K = _f64(perm)
+        if K.shape != (3, 3, self.nc):
+            raise ValueError("perm must have shape (3, 3, num_cells)")
+        t = np.empty(self.nf, dtype=np.float64)
+        jac = np.empty((self.ncf, 9), dtype=np.float64)
+        self._check(self.lib.pfv_tpfa_transmissibility_ad(self._h, _ptr(K, _dp), _ptr(t, _dp), _ptr(jac, _dp)))
+        return t, jac
 
     def set_stream(self, stream_ptr: int | None):
         """Run on the caller's HIP stream (0 / None = the legacy default stream, torch's default)."""

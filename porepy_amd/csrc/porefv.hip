@@ -367,6 +367,27 @@ pfv_status pfv_tpfa_discretize(pfv_ctx* h, int vector_source_dim) {
   });
 }
 
+pfv_status pfv_tpfa_transmissibility_ad(pfv_ctx* h, const double* perm_33n, double* t_face, double* dt_dk) {
+  return guarded(h, [&] {
+    require(h->have_grid, "the grid must be set first");
+    require(perm_33n && t_face && dt_dk, "null argument");
+    auto s = h->stream;
+    const size_t nc = (size_t)h->nc, nf = (size_t)h->nf, ncf = (size_t)h->ncf;
+    pfv::Buf<double> perm, t, jac;
+    double* dp = perm.ensure(9 * nc);
+    vec_in(h, dp, perm_33n, 9 * nc);
+    double* dt = h->vectors_on_device ? t_face : t.ensure(std::max<size_t>(nf, 1));
+    double* dj = h->vectors_on_device ? dt_dk : jac.ensure(std::max<size_t>(9 * ncf, 1));
+    pfv::tpfa_transmissibility_ad(*h, dp, dt, dj);
+    if (!h->vectors_on_device) {
+      be_d2h(t_face, dt, sizeof(double) * nf, s);
+      be_d2h(dt_dk, dj, sizeof(double) * 9 * ncf, s);
+    } else {
+      pfv::be_sync(s);
+    }
+  });
+}
+
 pfv_status pfv_mpfa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces, const int32_t* faces,
                                      int keep_other_rows) {
   return guarded(h, [&] {

@@ -115,3 +115,60 @@ class Tpfa:
         ctx = self._ctx(sd)
         ctx.assemble(np.asarray(pd["bc_values"], dtype=float), pd.get("vector_source", None), source)
         return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, restart=restart, precond=precond)
+
+
+class DifferentiableTpfa:
+    """Differentiable two-point transmissibilities on the device: the numerical core of the reference's
+    ``AdTpfaFlux.__transmissibility_matrix`` (models/constitutive_laws.py:1504-1578), which composes
+    ``t_f_full = 1 / (hf_to_f @ (1 / (d_n_by_dist @ k_c)))`` from the half-face matrices of
+    ``DifferentiableTpfa`` (numerics/fv/tpfa.py:546-620) and lets the forward AD carry the Jacobian through
+    two sparse products.  Here value and Jacobian come out of one pass over the half-faces
+    (``pfv_tpfa_transmissibility_ad``).
+
+    ``k_c`` is the reference's cell-wise tensor vector: 9 entries per cell, cell-major, ``K[r][s]`` at
+    ``3 r + s``.  ``transmissibility(sd, k_c)`` returns ``(t_f, dt_f/dk_c)`` with the Jacobian as a
+    ``(num_faces, 9 num_cells)`` CSR matrix; a permeability that depends on the primary variables is
+    chained on the caller's side, ``jac_u = dt_dk @ k_c.jac`` - what the reference's AdArray arithmetic
+    does (``mpfa``-based fluxes use the same matrix for their ``p_diff * d(T_TPFA)`` term,
+    constitutive_laws.py:1580-1625)."""
+
+    def __init__(self, device: int = 0, library=None):
+        self.device = device
+        self._library = library
+        self._contexts: dict = {}
+
+    def context(self, sd) -> _lib.Context:
+        ent = self._contexts.get(id(sd))
+        if ent is None or ent[0] is not sd:
+            ctx = _lib.Context(self.device, self._library)
+            raw = grid_to_raw(sd)
+            ctx.set_grid(raw)
+            self._contexts[id(sd)] = (sd, ctx, raw)
+            return ctx
+        return ent[1]
+
+    def half_face_cells(self, sd) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(face, cell, sign) of every half-face in the library's order (the entries of ``cell_faces``, cell
+        by cell).  The reference numbers its half-faces face by face (``sps.find(sd.cell_faces)``):
+        ``np.lexsort((cell, face))`` of these arrays is the permutation into its order."""
+        self.context(sd)
+        raw = self._contexts[id(sd)][2]
+        cells = np.repeat(np.arange(raw["cf_indptr"].size - 1), np.diff(raw["cf_indptr"]))
+        return raw["cf_indices"].astype(np.int64), cells, raw["cf_sign"].astype(np.int64)
+
+    def transmissibility(self, sd, k_c) -> tuple[np.ndarray, sps.csr_matrix]:
+        nc = sd.num_cells
+        k = np.asarray(k_c, dtype=np.float64)
+        if k.shape == (3, 3, nc):
+            K = k
+        elif k.shape == (9 * nc,):
+            K = np.ascontiguousarray(k.reshape(nc, 9).T).reshape(3, 3, nc)
+        else:
+            raise ValueError("k_c must be the 9 * num_cells vector of the reference or a (3, 3, num_cells) array")
+        ctx = self.context(sd)
+        t, d = ctx.tpfa_transmissibility_ad(K)
+        fi, ci, _ = self.half_face_cells(sd)
+        rows = np.repeat(fi, 9)
+        cols = (9 * ci[:, None] + np.arange(9)[None, :]).ravel()
+        jac = sps.csr_matrix((d.ravel(), (rows, cols)), shape=(sd.num_faces, 9 * nc))
+        return t, jac

@@ -944,3 +944,38 @@ def morton_numbered_grid_solve(lib, n=8):
             its[name, precond] = info["iterations"]
             assert ctx.stats()["solve_renumbered"] == (1 if name == "generator" else 0), name
     return its
+
+
+class TpfaAdCase:
+    """tests/golden/tpfaad_*.npz: t_f_full and its Jacobian w.r.t. k_c from the reference's forward AD."""
+
+    def __init__(self, name: str):
+        import os
+
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+        self.grid = {k[5:]: (z[k] if z[k].shape else z[k].item()) for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.perm = z["perm"]
+        self.t_face = z["ref_t_face"]
+        self.dt_dk = sps_csr((z["ref_dt_dk_data"], z["ref_dt_dk_indices"], z["ref_dt_dk_indptr"]),
+                                    shape=tuple(z["ref_dt_dk_shape"]))
+        self.hf_face, self.hf_cell, self.hf_sign = z["ref_hf_face"], z["ref_hf_cell"], z["ref_hf_sign"]
+        self.t_half_face_inv = z["ref_t_half_face_inv"]
+
+
+def check_tpfa_ad_case(lib, name: str):
+    """pfv_tpfa_transmissibility_ad through the host mirror against the reference's AD result."""
+    c = TpfaAdCase(name)
+    g = pa.grid_from_raw(c.grid)
+    d = pa.DifferentiableTpfa(library=lib)
+    nc = g.num_cells
+    k_c = np.ascontiguousarray(c.perm.reshape(9, nc).T).ravel()  # the reference's vector form
+    t, jac = d.transmissibility(g, k_c)
+    assert np.max(np.abs(t - c.t_face)) <= TOL * np.max(np.abs(c.t_face))
+    assert abs(jac - c.dt_dk).max() <= TOL * abs(c.dt_dk).max()
+    t2, jac2 = d.transmissibility(g, c.perm)                       # (3, 3, Nc) form
+    assert np.array_equal(t, t2) and abs(jac - jac2).max() == 0.0
+    fi, ci, sg = d.half_face_cells(g)
+    to_ref = np.lexsort((ci, fi))  # the reference's half-face order: face by face
+    assert np.array_equal(fi[to_ref], c.hf_face) and np.array_equal(ci[to_ref], c.hf_cell)
+    assert np.array_equal(sg[to_ref], c.hf_sign)

@@ -290,3 +290,8 @@ def test_full_size_rows_match_oracle_on_patches(lib):
     """BASELINE configs[2] at full size (1 971 054 tetrahedra, the bench workload)."""
     out = P.full_size_patch_parity(lib, 69)
     assert out["rows_checked"] > 100
+
+
+@pytest.mark.parametrize("name", ["tpfaad_cart2d_4x3", "tpfaad_tri2d_3x3", "tpfaad_tet3d_2x2x2", "tpfaad_cart2d_tilted_3x2"])
+def test_differentiable_tpfa_matches_reference_ad(lib, name):
+    P.check_tpfa_ad_case(lib, name)
