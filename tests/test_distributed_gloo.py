@@ -117,6 +117,35 @@ def test_two_rank_sharded_assembly_and_solve(tmp_path, kind, method, precond):
     assert seen.all()
 
 
+def test_hook_failure_aborts_the_sharded_solve():
+    """An exception in an exchange hook must not travel through the C frames: the library stops the solve
+    (status 4) and the Python side re-raises the original exception."""
+    lib = P.emulation_library()
+    g, K, bc, bv, src = _problem("cart")
+    raw = pa.grid_to_raw(g)
+    lp = D.extract_subdomain(raw, np.zeros(g.num_cells, dtype=np.int32), 0)
+    sh = D.ShardedMpfa(lp, device="cpu", library=lib, dist=None)
+    sh.discretize(K.values[:, :, lp.cell_gid], sh.local_bc_flags(pa.bc_flags(bc)[lp.face_gid]),
+                  bc.robin_weight[lp.face_gid], pa.determine_eta(g))
+    sh.assemble(bv[lp.face_gid], src[lp.cell_gid])
+    x, info = sh.solve("cg", rtol=1e-10)
+    assert info["converged"] and info["driver"] == "library"
+
+    class Boom(RuntimeError):
+        pass
+
+    def broken(_x):
+        raise Boom("link down")
+
+    sh.plan.exchange = broken
+    with pytest.raises(Boom):
+        sh.solve("cg", rtol=1e-10)
+    # the handle stays usable
+    del sh.plan.exchange
+    x2, info2 = sh.solve("cg", rtol=1e-10)
+    assert info2["converged"] and np.array_equal(x.numpy(), x2.numpy())
+
+
 def test_halo_plan_single_rank_is_noop():
     g, K, bc, bv, src = _problem("cart")
     raw = pa.grid_to_raw(g)
