@@ -622,35 +622,6 @@ PFV_HD inline void atomic_min_i32(int* addr, int v) {
 #endif
 #endif
 }
-// compare-and-swap / exchange on a 32-bit word (LDS hash tables); both return the old value
-PFV_HD inline int atomic_cas_i32(int* addr, int expected, int desired) {
-#ifdef PFV_EMULATE
-  const int old = *addr;
-  if (old == expected) *addr = desired;
-  return old;
-#else
-#if defined(__HIP_DEVICE_COMPILE__)
-  return atomicCAS(addr, expected, desired);
-#else
-  (void)addr; (void)expected; (void)desired;
-  return 0;
-#endif
-#endif
-}
-PFV_HD inline int atomic_exch_i32(int* addr, int v) {
-#ifdef PFV_EMULATE
-  const int old = *addr;
-  *addr = v;
-  return old;
-#else
-#if defined(__HIP_DEVICE_COMPILE__)
-  return atomicExch(addr, v);
-#else
-  (void)addr; (void)v;
-  return 0;
-#endif
-#endif
-}
 PFV_HD inline void atomic_add_i32(int* addr, int v) {
 #ifdef PFV_EMULATE
   *addr += v;

@@ -196,6 +196,7 @@ struct pfv_ctx_impl {
   const double* perm_for_val = nullptr;  // the values the renumbered copy was made from (nullptr: stale)
   const int32_t* win_for = nullptr;      // the index array win_sys was built for (nullptr: stale)
   bool win_sys_prebuilt = false;         // win_sys was built for pat_A by the discretize call (beside the face kernel)
+  bool win_rows_prebuilt = false;        // same for win_rows (sharded solve: the rows of the owned cells)
   int active_bs = 1;                 // unknowns per cell of the active system (AMG block size)
   int precond = 0;                   // PFV_PRECOND_*
   std::unique_ptr<Amg> amg;          // hierarchy of the active system (rebuilt when the system changes)

@@ -56,6 +56,25 @@ void upload(pfv::Buf<T>& buf, const T* host, size_t n, pfv::stream_t s) {
 
 }  // namespace
 
+namespace {
+// the leading rows of a pattern as a pattern of its own (shares the index arrays, frees nothing)
+struct RowsView {
+  pfv::CsrPattern V;
+  RowsView(const pfv::CsrPattern& P, int64_t nrows) {
+    V.nrows = nrows;
+    V.ncols = P.ncols;
+    V.nnz = P.nnz;  // (the window's entry positions index the full arrays)
+    V.max_row = P.max_row;
+    V.indptr.p = P.indptr.p;
+    V.indices.p = P.indices.p;
+  }
+  ~RowsView() {
+    V.indptr.p = nullptr;
+    V.indices.p = nullptr;
+  }
+};
+}  // namespace
+
 extern "C" {
 
 int pfv_is_device_build(void) {
@@ -181,7 +200,7 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     h->perm_for_val = nullptr;
     h->win_for = h->win_rows_for = nullptr;
     h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
-    h->win_sys_prebuilt = false;
+    h->win_sys_prebuilt = h->win_rows_prebuilt = false;
     h->biot_rows_complete = false;
     h->rows_complete = false;
     h->rows_complete_m = false;
@@ -199,7 +218,7 @@ pfv_status pfv_set_periodic(pfv_ctx* h, const int32_t* native_cell, const double
     require(h->have_grid, "pfv_set_grid first");
     require((native_cell == nullptr) == (shift == nullptr), "give both arrays, or neither to clear");
     h->have_numeric = h->have_system = false;
-    h->win_sys_prebuilt = false;
+    h->win_sys_prebuilt = h->win_rows_prebuilt = false;
     h->rows_complete = false;
     if (!native_cell) {
       h->periodic = false;
@@ -231,7 +250,7 @@ pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t
     h->have_params = true;
     h->subface_bc = false;
     h->have_numeric = h->have_system = false;
-    h->win_sys_prebuilt = false;
+    h->win_sys_prebuilt = h->win_rows_prebuilt = false;
   });
 }
 
@@ -240,7 +259,7 @@ pfv_status pfv_mpfa_set_subface_bc(pfv_ctx* h, const uint8_t* bc_flags_sub, cons
     require(h->have_grid && h->have_params, "pfv_mpfa_set_params first");
     h->subface_bc = false;
     h->have_numeric = h->have_system = false;
-    h->win_sys_prebuilt = false;
+    h->win_sys_prebuilt = h->win_rows_prebuilt = false;
     h->rows_complete = false;
     if (!bc_flags_sub) return;
     const size_t nsf = (size_t)h->nsf;
@@ -312,24 +331,40 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
       // The SpMV window of A (spmv_win.inc) only needs A's pattern, which the symbolic phase has left:
       // when the solve is going to work on the system in place (grid numbered along the Morton curve),
       // it is built now on the second stream, beside the face kernel, instead of inside pfv_solve.
-      h->win_sys_prebuilt = false;
+      h->win_sys_prebuilt = h->win_rows_prebuilt = false;
       const bool prebuild = h->aux_stream && h->have_cell_order && h->cell_order_identity &&
                             pfv::env_int("PFV_OVERLAP_WINDOW", 1) != 0 && pfv::env_int("PFV_REORDER", 1) != 0 &&
                             h->pat_A.nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000);
-      if (prebuild) {
+      // (a sharded solve multiplies the rows of the owned cells: the window of those rows, for the
+      // number of owned rows of the previous solve on this handle)
+      h->win_rows_prebuilt = false;
+      const bool prebuild_rows = !prebuild && h->aux_stream && h->win_rows_n > 0 && h->win_rows_n <= h->pat_A.nrows &&
+                                 pfv::env_int("PFV_OVERLAP_WINDOW", 1) != 0 &&
+                                 h->pat_A.nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000);
+      if (prebuild || prebuild_rows) {
         pfv::StreamFork fork(s, h->aux_stream);
         pfv::run_face_kernel(*h, with_vs);
         h->stream = h->aux_stream;
         try {
-          pfv::win_build(*h, h->pat_A, h->win_sys);
+          if (prebuild) {
+            pfv::win_build(*h, h->pat_A, h->win_sys);
+          } else {
+            RowsView rows(h->pat_A, h->win_rows_n);
+            pfv::win_build(*h, rows.V, h->win_rows);
+          }
         } catch (...) {
           h->stream = s;
           throw;
         }
         h->stream = s;
         fork.join();
-        h->win_for = h->pat_A.indices.p;
-        h->win_sys_prebuilt = true;
+        if (prebuild) {
+          h->win_for = h->pat_A.indices.p;
+          h->win_sys_prebuilt = true;
+        } else {
+          h->win_rows_for = h->pat_A.indices.p;
+          h->win_rows_prebuilt = true;
+        }
       } else
 #endif
       pfv::run_face_kernel(*h, with_vs);
@@ -363,7 +398,7 @@ pfv_status pfv_tpfa_discretize(pfv_ctx* h, int vector_source_dim) {
     h->have_topology = false;  // an MPFA call on this handle rebuilds its own topology + patterns
     h->have_numeric = true;
     h->have_system = false;
-    h->win_sys_prebuilt = false;
+    h->win_sys_prebuilt = h->win_rows_prebuilt = false;
   });
 }
 
@@ -442,7 +477,7 @@ pfv_status pfv_mpfa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces
     h->stats.face_ms = tm.stop(s);
     h->have_numeric = true;
     h->have_system = false;
-    h->win_sys_prebuilt = false;
+    h->win_sys_prebuilt = h->win_rows_prebuilt = false;
     h->filled[PFV_MAT_SYSTEM] = false;
   });
 }
@@ -496,8 +531,10 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
       pfv::assemble_system(*h);
       if (h->amg) h->amg->valid = false;
       h->perm_for_val = nullptr;
-      h->win_rows_for = nullptr;
-      if (h->win_sys_prebuilt) h->win_sys_prebuilt = false;  // built for this very pattern by the discretize call: keep
+      // windows built for this very pattern by the discretize call are kept
+      if (h->win_rows_prebuilt) h->win_rows_prebuilt = false;
+      else h->win_rows_for = nullptr;
+      if (h->win_sys_prebuilt) h->win_sys_prebuilt = false;
       else h->win_for = nullptr;
     }
     pfv::assemble_rhs(*h, d_bc, d_vs, d_src);
@@ -1159,24 +1196,6 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
   return st;
 }
 
-namespace {
-// the leading rows of a pattern as a pattern of its own (shares the index arrays, frees nothing)
-struct RowsView {
-  pfv::CsrPattern V;
-  RowsView(const pfv::CsrPattern& P, int64_t nrows) {
-    V.nrows = nrows;
-    V.ncols = P.ncols;
-    V.nnz = P.nnz;  // (the window's entry positions index the full arrays)
-    V.max_row = P.max_row;
-    V.indptr.p = P.indptr.p;
-    V.indices.p = P.indices.p;
-  }
-  ~RowsView() {
-    V.indptr.p = nullptr;
-    V.indices.p = nullptr;
-  }
-};
-}  // namespace
 
 pfv_status pfv_solve_sharded(pfv_ctx* h, int method, double rtol, int maxit, int64_t n_own,
                              const pfv_shard_hooks* hooks, double* d_work, double* d_x_owned,
