@@ -45,3 +45,22 @@ def test_momentum_balance_and_poromechanics_models_with_rebound_mpsa_biot():
     assert out["mech_dofs"] == 72 and out["poro_dofs"] == 108
     assert out["mech_x_rel_err"] < 1e-10 and out["mech_A_rel_err"] < 1e-10
     assert out["poro_x_rel_err"] < 1e-10 and out["poro_A_rel_err"] < 1e-10
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference PorePy not present")
+def test_differentiable_tpfa_transmissibilities_in_the_reference_model():
+    """The reference's unit-test model of its differentiable TPFA flux (two cells, pressure-dependent
+    full-tensor permeability): ``AdTpfaFlux.__transmissibility_matrix`` through its operator tree and
+    forward AD against pfv_tpfa_transmissibility_ad chained with the Jacobian of k_c."""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "oracle", "shim"), REF])
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dropin_adtpfa_script.py")], env=env, cwd="/tmp",
+                       capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, r.stderr[-2000:]
+    out = json.loads(line[-1][7:])
+    for base in ("tpfa", "mpfa"):
+        o = out[base]
+        assert o["faces"] == 7 and o["dofs"] == 2 and o["jac_nnz_ref"] > 0
+        assert o["t_rel_err"] < 1e-12 and o["jac_rel_err"] < 1e-12
