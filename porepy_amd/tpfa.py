@@ -136,6 +136,7 @@ class DifferentiableTpfa:
         self.device = device
         self._library = library
         self._contexts: dict = {}
+        self.calls = 0  # evaluations through the device kernel
 
     def context(self, sd) -> _lib.Context:
         ent = self._contexts.get(id(sd))
@@ -167,8 +168,62 @@ class DifferentiableTpfa:
             raise ValueError("k_c must be the 9 * num_cells vector of the reference or a (3, 3, num_cells) array")
         ctx = self.context(sd)
         t, d = ctx.tpfa_transmissibility_ad(K)
+        self.calls += 1
         fi, ci, _ = self.half_face_cells(sd)
         rows = np.repeat(fi, 9)
         cols = (9 * ci[:, None] + np.arange(9)[None, :]).ravel()
         jac = sps.csr_matrix((d.ravel(), (rows, cols)), shape=(sd.num_faces, 9 * nc))
         return t, jac
+
+
+def as_porepy_ad_tpfa_flux(device: int = 0, library=None):
+    """Mixin for models of the reference that use its differentiable two-point flux (``pp.constitutive_laws.
+    AdTpfaFlux`` through ``DarcysLawAd`` / ``FouriersLawAd``): put the returned class BEFORE those in the
+    bases and ``AdTpfaFlux.__transmissibility_matrix`` (models/constitutive_laws.py:1504-1578) evaluates the
+    face transmissibilities and their Jacobian with the device kernel instead of two sparse products through
+    the forward AD; everything built on ``t_f_full`` upstream (``diffusive_flux``, ``potential_trace``, the
+    MPFA / TPFA mixture) is untouched.
+
+        class Model(porepy_amd.as_porepy_ad_tpfa_flux(), pp.constitutive_laws.DarcysLawAd, pp.SinglePhaseFlow): ...
+    """
+    import porepy as pp  # the reference; absent on the GPU box
+
+    hip = DifferentiableTpfa(device, library)
+
+    class HipAdTpfaFlux:
+        hip_differentiable_tpfa = hip
+
+        # the name the reference's ``self.__transmissibility_matrix(...)`` resolves to inside AdTpfaFlux
+        def _AdTpfaFlux__transmissibility_matrix(self, subdomains, diffusivity_tensor):
+            basis = self.basis(subdomains, dim=9)
+            volumes = pp.ad.sum_operator_list([e @ self.specific_volume(subdomains) for e in basis])
+            k_c = volumes * diffusivity_tensor(subdomains)
+            diff_discr = pp.numerics.fv.tpfa.DifferentiableTpfa()
+            _, d_vec, _ = diff_discr.half_face_geometry_matrices(subdomains)
+            hf_to_f = diff_discr.half_face_map(subdomains, to_entity="faces", with_sign=True)
+            sds = list(subdomains)
+
+            def transmissibility(k):
+                kv = np.asarray(getattr(k, "val", k), dtype=np.float64)
+                vals, jacs, o = [], [], 0
+                for sd in sds:
+                    n9 = 9 * sd.num_cells
+                    if sd.num_cells == 0 or sd.num_faces == 0:
+                        vals.append(np.zeros(sd.num_faces))
+                        jacs.append(sps.csr_matrix((sd.num_faces, n9)))
+                    else:
+                        v, j = hip.transmissibility(sd, kv[o:o + n9])
+                        vals.append(v)
+                        jacs.append(j)
+                    o += n9
+                val = np.concatenate(vals) if vals else np.zeros(0)
+                if not hasattr(k, "jac"):
+                    return val
+                dt_dk = sps.block_diag(jacs, format="csr") if jacs else sps.csr_matrix((0, 0))
+                return pp.ad.AdArray(val, dt_dk @ k.jac)
+
+            t_f_full = pp.ad.Function(transmissibility, "hip_tpfa_transmissibility")(k_c)
+            t_f_full.set_name("transmissibility matrix")
+            return t_f_full, diff_discr, hf_to_f, d_vec
+
+    return HipAdTpfaFlux

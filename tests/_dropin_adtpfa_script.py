@@ -46,6 +46,36 @@ def main():
             "jac_rel_err": float(abs(jac - t_ref.jac).max() / abs(t_ref.jac).max()),
             "jac_nnz_ref": int(t_ref.jac.nnz), "jac_max": float(abs(t_ref.jac).max()),
         }
+    # the whole flux with the mixin in front of the reference's classes: value and Jacobian of
+    # darcy_flux / potential trace must not change
+    Mixin = pa.as_porepy_ad_tpfa_flux(library=P.emulation_library())
+
+    class HipModel(Mixin, UnitTestAdTpfaFlux):
+        pass
+
+    for base in ("tpfa", "mpfa"):
+        res = {}
+        for name, cls in (("ref", UnitTestAdTpfaFlux), ("hip", HipModel)):
+            model = cls({"darcy_flux_discretization": base, "vector_source": np.array([1.0, 2.0, 3.0, 5.0]),
+                         "times_to_export": []})
+            model.prepare_simulation()
+            sds = model.mdg.subdomains()
+            model.discretize()
+            flux = model.darcy_flux(sds).value_and_jacobian(model.equation_system)
+            trace = model.potential_trace(sds, model.pressure, model.permeability,
+                                          model.combine_boundary_operators_darcy_flux, "darcy_flux"
+                                          ).value_and_jacobian(model.equation_system)
+            res[name] = (flux, trace)
+        fr, tr = res["ref"]
+        fh, th = res["hip"]
+        out[base + "_model"] = {
+            "flux_rel_err": float(np.max(np.abs(fh.val - fr.val)) / np.max(np.abs(fr.val))),
+            "flux_jac_rel_err": float(abs(fh.jac - fr.jac).max() / abs(fr.jac).max()),
+            "trace_rel_err": float(np.max(np.abs(th.val - tr.val)) / np.max(np.abs(tr.val))),
+            "trace_jac_rel_err": float(abs(th.jac - tr.jac).max() / abs(tr.jac).max()),
+            "flux_jac_nnz": int(fr.jac.nnz),
+            "device_path_calls": int(Mixin.hip_differentiable_tpfa.calls),
+        }
     print("RESULT " + json.dumps(out))
 
 

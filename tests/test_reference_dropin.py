@@ -64,3 +64,8 @@ def test_differentiable_tpfa_transmissibilities_in_the_reference_model():
         o = out[base]
         assert o["faces"] == 7 and o["dofs"] == 2 and o["jac_nnz_ref"] > 0
         assert o["t_rel_err"] < 1e-12 and o["jac_rel_err"] < 1e-12
+        # the mixin of porepy_amd.as_porepy_ad_tpfa_flux() in front of the reference's classes: flux and
+        # pressure trace of the whole model, values and Jacobians
+        m = out[base + "_model"]
+        assert m["device_path_calls"] >= 1 and m["flux_jac_nnz"] > 0
+        assert max(m["flux_rel_err"], m["flux_jac_rel_err"], m["trace_rel_err"], m["trace_jac_rel_err"]) < 1e-12
