@@ -4,15 +4,16 @@
 One "step" = one pass of the hot path over one grid already resident in HBM:
   sub-cell topology + CSR symbolic phase + interaction-region kernel + face kernel
   (= what one ``Mpfa.discretize`` call of the reference does), ``A = div @ flux`` and the
-  right-hand side, then the Jacobi-preconditioned BiCGStab solve to rtol.
+  right-hand side, then the preconditioned BiCGStab solve to rtol (aggregation-AMG cycle by default).
 Default workload (N = 1): BASELINE.json configs[2] — ~2 M tetrahedra, perturbed nodes,
 full-tensor anisotropic permeability — the grid the north-star target is quoted on.
 
 Launch: ``python bench.py --gpus N --steps K --warmup W``; for N > 1 under
 ``python -m torch.distributed.run --nproc-per-node N``.  The path shards by subdomain: each
 rank owns n lattice layers of one global box that grows with N (weak scaling) plus one halo
-layer per cut; assembly needs no collective, the BiCGStab solve exchanges halo entries of the
-SpMV input point-to-point and fuses every pair of dot products into one all-reduce.
+layer per cut; assembly needs no collective, the BiCGStab solve (the library's fused loop,
+pfv_solve_sharded) exchanges halo entries of the SpMV input point-to-point and fuses every pair of
+dot products into one all-reduce - this process only serves those two hooks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`` for the
 dominant kernel (CSR SpMV of the solve; live HIP-event timing through pfv_time_kernel) and

@@ -12,8 +12,12 @@ add the cells within one node-ring as overlap, keep only the rows of owned faces
   of the input vector are fetched from their owners (point-to-point over xGMI through
   RCCL; ``gloo`` on CPU in the tests) and each reduction is one fused all-reduce of 1-2 doubles.
 
-Vectors live in torch tensors (device memory + process group plumbing); the SpMV is the HIP
-kernel of the C ABI (``pfv_spmv_device_rows``) running on torch's current stream.
+The Krylov loop itself is the library's fused one (``pfv_solve_sharded``: windowed SpMV on the owned
+rows with the dot products fused in, Krylov scalars resident in HBM); this module only serves its
+two exchange hooks with ``torch.distributed`` on torch's current stream, which the handle is told
+to run on.  torch owns the device buffers the hooks address and the process group - plumbing.  The
+same iteration spelled out in torch ops around ``pfv_spmv_device_rows`` is kept as
+``solve(driver="torch")``, the cross-check of the tests.
 """
 from __future__ import annotations
 
