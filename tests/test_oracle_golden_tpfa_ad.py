@@ -42,3 +42,20 @@ def test_chain_rule_against_finite_differences():
     nc = c.perm.shape[2]
     dk = np.ascontiguousarray(dK.reshape(9, nc).T).ravel()
     assert np.max(np.abs((tp - tm) / 2 - jac @ dk)) <= 1e-6 * np.max(np.abs(jac @ dk))
+
+
+@pytest.mark.parametrize("name", ["tpfa_line_8", "tpfa_line_6_in_3d_via_mpfa"])
+def test_one_dimensional_grids(name):
+    """Fracture intersections of a mixed-dimensional model are 1-D grids (possibly embedded in 3-D): the
+    kernel against the oracle on the grids of the TPFA fixtures."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    raw = {k[5:]: (z[k] if z[k].shape else z[k].item()) for k in z.files if k.startswith("grid_")}
+    raw["dim"] = int(raw["dim"])
+    g = pa.grid_from_raw(raw)
+    t, jac = pa.DifferentiableTpfa(library=P.emulation_library()).transmissibility(g, z["perm"])
+    t_o, jac_o, _ = to.transmissibility(raw, z["perm"])
+    assert g.dim == 1
+    assert np.max(np.abs(t - t_o)) <= 1e-12 * np.max(np.abs(t_o))
+    assert abs(jac - jac_o).max() <= 1e-12 * abs(jac_o).max()
