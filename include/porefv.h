@@ -355,8 +355,8 @@ enum { PFV_KERNEL_SPMV_A = 0, PFV_KERNEL_NODE = 1, PFV_KERNEL_FACE = 2,
        PFV_KERNEL_AMG_SMOOTH = 3 /* finest-level smoothing product of the AMG cycle (needs a built hierarchy) */ };
 pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms);
 
-/* Test hook: copy an internal FP64 device array to the host (0 = rows of A^-1 of all nodes,
- * 1 = rows of the flux operator T, both in node_mptr order; count <= its length). */
+/* Test hook: copy the leading `count` entries of an internal FP64 device array to the host (0 = the
+ * per-node response tables, 1 = the boundary columns of the nodes on the boundary). */
 pfv_status pfv_debug_copy(pfv_ctx* h, int which, double* dst, int64_t count);
 
 #ifdef __cplusplus

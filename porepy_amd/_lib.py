@@ -630,9 +630,8 @@ class Context:
     def reset_stream(self):
         self._check(self.lib.pfv_reset_stream(self._h))
 
-    def debug_array(self, which: int) -> np.ndarray:
-        """Internal per-node operator rows (0: A^-1, 1: T), for tests."""
-        n = self.stats()["sum_block_sq"]
+    def debug_array(self, which: int, n: int) -> np.ndarray:
+        """Leading n entries of an internal per-node array (0: response tables, 1: boundary columns), for tests."""
         out = np.empty(n, dtype=np.float64)
         self._check(self.lib.pfv_debug_copy(self._h, int(which), _ptr(out, _dp), n))
         return out

@@ -408,6 +408,26 @@ __global__ void __launch_bounds__(64) k_wave_for(int64_t n, size_t lds_per_item,
     __syncthreads();
   }
 }
+// Same, with the items split into 8 contiguous ranges, one per XCD (workgroup b is observed to run on
+// XCD b % 8; a speed assumption only): work items that are neighbours in the item order share one L2.
+// gridDim.x is a multiple of 8.
+template <int G, class F>
+__global__ void __launch_bounds__(64) k_wave_for_xcd(int64_t n, size_t lds_per_item, F f) {
+  extern __shared__ __attribute__((aligned(16))) char pfv_lds[];
+  constexpr int per_block = 64 / G;
+  const int grp = (int)threadIdx.x / G;
+  const int64_t nvb = (n + per_block - 1) / per_block;  // virtual blocks
+  const int64_t chunk = (nvb + 7) >> 3;
+  const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  for (int64_t vb = slot; vb < chunk; vb += per_xcd) {
+    const int64_t b = (xcd * chunk + vb) * per_block + grp;
+    if (b < n) {
+      WaveCtx w{b, pfv_lds + (size_t)grp * lds_per_item, (int)threadIdx.x % G, G, nullptr};
+      f(w);
+    }
+    __syncthreads();
+  }
+}
 #endif
 
 // One thread per index.
@@ -462,6 +482,29 @@ inline void wave_for_g(int G, stream_t s, int64_t n, size_t lds_bytes, F f) {
   if (G <= 16) wave_for<16>(s, n, lds_bytes, f);
   else if (G <= 32) wave_for<32>(s, n, lds_bytes, f);
   else wave_for<64>(s, n, lds_bytes, f);
+}
+
+// One wavefront per work item, the items dealt to the XCDs in 8 contiguous ranges (k_wave_for_xcd).
+template <class F>
+inline void wave_for_xcd(stream_t s, int64_t n, size_t lds_bytes, F f) {
+#ifdef PFV_EMULATE
+  wave_for<64>(s, n, lds_bytes, f);
+#else
+  if (n < 4096) {
+    wave_for<64>(s, n, lds_bytes, f);
+    return;
+  }
+  lds_bytes = (lds_bytes + 15) & ~size_t(15);
+  if (lds_bytes > 160 * 1024) throw Error(5, "work item needs more than 160 KiB of LDS");
+  int64_t blocks = n > 256 * 64 ? 256 * 64 : ((n + 7) & ~int64_t(7));
+  if (lds_bytes > 48 * 1024) {
+    PFV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_for_xcd<64, F>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wave_for_xcd<64, F>), dim3((unsigned)blocks), dim3(64), lds_bytes, s, n,
+                     lds_bytes, f);
+  PFV_HIP_CHECK(hipGetLastError());
+#endif
 }
 inline int env_int(const char* name, int dflt) {
   const char* e = std::getenv(name);

@@ -15,14 +15,22 @@ constexpr int kMaxBlock = 255;     // local sub-face / sub-cell indices are stor
 static const int kClassBounds[] = {4, 8, 12, 16, 24, 32, 40, 48, 64, 96, 128, 192, 255};
 constexpr int kNumClasses = 13;
 
-// per sub-face (face, node) lookup record used by the face kernel: one 16-byte load replaces the
-// chain face_nodes -> node -> {node_fptr, node_mptr, node_hptr}
-struct SfMeta {
-  int64_t m0row;  // offset of this sub-face's row in the node's n x n blocks (Ainv / Tmat)
-  int32_t h0;     // first sub-half-face of the node
-  uint16_t n;     // sub-faces of the node (row length)
-  uint16_t deg;   // cells of the node
+// Per sub-face (face, node) record consumed by the face kernel: one 64-byte line, written whole by the
+// interaction-region kernel (by the lane of the sub-cell the flux is evaluated from).  It replaces the
+// chain face_nodes -> node -> {node_fptr, node_tptr, node_hptr} and carries the nd weights that turn rows
+// of the node's response table into the flux row (mpfa_numeric.inc).
+struct alignas(16) SfRec {
+  int64_t toff;    // offset (doubles) of the node's response table in `tab`
+  uint8_t n;       // sub-faces of the node = rows of the table before the e-row
+  uint8_t ls;      // local index of this sub-face = its row
+  uint8_t jstar;   // local sub-cell the flux is evaluated from
+  uint8_t deg;     // cells of the node
+  uint8_t r[3];    // local sub-faces of sub-cell jstar (one of them is ls)
+  uint8_t pad;
+  double om[3];    // omega_{h*} = nK_{h*} D^-1: flux row = direct term - sum_k om[k] * table row r[k]
+  double nk[3];    // nK_{h*}: direct vector-source term
 };
+static_assert(sizeof(SfRec) == 64, "SfRec is one 64-byte record");
 
 struct CsrPattern {
   int64_t nrows = 0, ncols = 0, nnz = 0;
@@ -107,8 +115,8 @@ struct pfv_ctx_impl {
   Buf<int32_t> node_bptr;     // [nn+1] boundary faces around each node
   Buf<int32_t> node_bfaces;   //   face ids, ascending
   Buf<uint8_t> node_bls;      //   their local subface index
-  Buf<int64_t> node_mptr;     // [nn+1] prefix of n(v)^2: offset of the node's n x n blocks
-  Buf<SfMeta> sf_meta;        // [nsf] see SfMeta
+  Buf<int64_t> node_tptr;     // [nn+1] offset of the node's response table in `tab`: (n + 1) rows of ldt doubles
+  Buf<int64_t> node_tbptr;    // [nn+1] offset of the node's boundary columns in `tabb`: 2 x n x nb doubles
   Buf<uint8_t> flux_colpairs; // [nnz(flux) * max_face_nodes] for every flux column: the (node of face, cell) pair per node, 0xff = none
   Buf<uint8_t> node_active;   // [nn] partial discretization: nodes of the requested faces
   Buf<int32_t> face_subset;   // partial discretization: the requested faces
@@ -120,16 +128,17 @@ struct pfv_ctx_impl {
   Buf<int32_t> node_order;    // [nn] nodes sorted by block-size class
   std::vector<int64_t> class_begin;  // host: first position of each size class in node_order
   int max_block = 0, max_deg = 0, max_face_nodes = 0, max_cell_faces = 0, max_bnd_per_node = 0;
-  int64_t sum_block_sq = 0;
+  int64_t sum_block_sq = 0;   // sum of n(v)^2 (statistics)
+  int64_t tab_len = 0, tabb_len = 0;
 
   // ---- per-node numeric results consumed by the face kernel ---------------------
-  Buf<double> Ainv, Tmat;     // [sum n^2] rows of A^-1 and of the flux operator T = W A^-1
-  Buf<double> h_bp;           // [nh]     cell-pressure rhs coefficient of h
-  Buf<double> h_bg;           // [nh*nd]  vector-source rhs coefficients of h
-  Buf<double> sf_sig;         // [nsf]    direct cell term of the subface flux
-  Buf<double> sf_nk;          // [nsf*nd] direct vector-source term
-  Buf<double> sf_beta;        // [nsf]    coefficient of the boundary value in the local rhs
-  Buf<uint8_t> sf_jstar;      // [nsf]    local subcell the flux is evaluated from
+  // Response table of node v (n sub-faces, nh = nd * deg sub-half-faces, row stride ldt = nh rounded up
+  // to even): row r < n holds TV[r][nd*j + b] = d lambda_r / d (vector source component b of cell j)
+  // = (A^-1 G)[r][.]; row n holds e[nd*j + b] = (D_j^-1 1)[b], which turns a vector-source entry into the
+  // cell-pressure entry (flux = vector_source . blockdiag(e)).
+  Buf<double> tab;            // [tab_len]
+  Buf<double> tabb;           // [tabb_len] boundary nodes: T[:, lb] beta_lb (n x nb), then A^-1[:, lb] beta_lb
+  Buf<SfRec> sf_rec;          // [nsf] see SfRec
   Buf<int32_t> status;        // [4] device status words: singular node, ...
 
   // ---- outputs --------------------------------------------------------------------

@@ -1320,8 +1320,8 @@ pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms) {
 
 pfv_status pfv_debug_copy(pfv_ctx* h, int which, double* dst, int64_t count) {
   return guarded(h, [&] {
-    require(h->have_numeric && dst && count >= 0 && count <= h->sum_block_sq, "bad argument");
-    const double* src = which == 0 ? h->Ainv.p : h->Tmat.p;
+    require(h->have_numeric && dst && count >= 0 && count <= (which == 0 ? h->tab_len : h->tabb_len), "bad argument");
+    const double* src = which == 0 ? h->tab.p : h->tabb.p;
     be_d2h(dst, src, sizeof(double) * (size_t)count, h->stream);
   });
 }
