@@ -32,6 +32,19 @@ struct alignas(16) SfRec {
 };
 static_assert(sizeof(SfRec) == 64, "SfRec is one 64-byte record");
 
+// Per face, in processing order (face_order): what the face kernel needs before it can issue its first
+// dependent load -- one 32-byte record instead of the chain order -> {fn_ptr, flux indptr, bound indptr}.
+struct alignas(16) FaceRec {  // dwords only: the kernel reads it with scalar loads
+  int32_t f;        // face (-1: none)
+  int32_t a;        // first sub-face (= fn_ptr[f])
+  int32_t p0;       // first entry of the flux row
+  int32_t q0;       // first entry of the bound_flux row
+  uint32_t lens;    // entries of the flux row | entries of the bound_flux row << 16
+  uint32_t nnf;     // nodes of the face
+  int32_t pad[2];
+};
+static_assert(sizeof(FaceRec) == 32, "FaceRec is one 32-byte record");
+
 struct CsrPattern {
   int64_t nrows = 0, ncols = 0, nnz = 0;
   Buf<int32_t> indptr, indices;
@@ -139,6 +152,7 @@ struct pfv_ctx_impl {
   Buf<double> tab;            // [tab_len]
   Buf<double> tabb;           // [tabb_len] boundary nodes: T[:, lb] beta_lb (n x nb), then A^-1[:, lb] beta_lb
   Buf<SfRec> sf_rec;          // [nsf] see SfRec
+  Buf<FaceRec> face_rec;      // [nf] see FaceRec (written at the end of the symbolic phase)
   Buf<int32_t> status;        // [4] device status words: singular node, ...
 
   // ---- outputs --------------------------------------------------------------------
