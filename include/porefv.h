@@ -104,6 +104,11 @@ typedef struct {
                                      second stream (symbolic_ms and node_ms then are overlapping spans) */
   int64_t solve_renumbered;       /* 1: the last pfv_solve worked on the copy renumbered along the Morton curve,
                                      0: in place (grid already numbered that way, or a user system) */
+  double node_flops;              /* FP64 operations the interaction-region kernel executes per launch on this grid:
+                                     sum over the nodes of 2 n^3 (Gauss-Jordan) + 2 nd n nh (response table)
+                                     + 2 nd nh (3 n_b) (boundary columns) + ~60 nd^2 per sub-cell (nK, D^-1, omega) */
+  int64_t node_table_doubles;     /* doubles in the per-node response tables (what the node kernel writes and the
+                                     face kernel reads) */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);
@@ -182,6 +187,19 @@ pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols
  * any pointer may be NULL to skip that array */
 pfv_status pfv_get_matrix(pfv_ctx* h, int which, int32_t* indptr, int32_t* indices,
                           double* data);
+/* the same for a list of rows only (gathered on the device, one copy): what a caller that slices
+ * `data[DISCRETIZATION_MATRICES][kw]["flux"][faces]` needs instead of the whole matrix (21.6 GB for the
+ * six matrices of a 2 M-cell grid).  out_indptr has n_rows + 1 entries (row i of the output = row rows[i]);
+ * call once with out_indices = out_data = NULL to learn the sizes, then again with the arrays. */
+/* free / total bytes of the handle's device (free includes the blocks parked in the handle's own cache);
+ * -1 / -1 from the host-emulation build.  The host mirror checks its footprint estimate against it before
+ * the first discretization of a grid (the reference's peak-memory estimate: mpfa.py:1315-1355). */
+pfv_status pfv_device_memory(pfv_ctx* h, int64_t* free_bytes, int64_t* total_bytes);
+/* number of unknowns of the system pfv_solve / pfv_get_rhs operate on (0: nothing assembled): the length of
+ * the arrays those calls write */
+pfv_status pfv_active_size(pfv_ctx* h, int64_t* n);
+pfv_status pfv_get_matrix_rows(pfv_ctx* h, int which, int64_t n_rows, const int32_t* rows, int32_t* out_indptr,
+                               int32_t* out_indices, double* out_data);
 
 /* FVElliptic.assemble_matrix_rhs (numerics/fv/fv_elliptic.py:67-112):
  * A = div @ flux, b = -div @ bound_flux @ bc_values - div @ vector_source @ g + source.
@@ -350,9 +368,12 @@ pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out);
 
 /* Measurement hook for bench.py: average duration (ms, HIP events on the handle's stream)
  * of `reps` back-to-back launches of one kernel on the data currently in the handle.
- * kernel: 0 = CSR SpMV with A, 1 = interaction-region (node) kernel, 2 = face kernel. */
+ * kernel: 0 = CSR SpMV with A, 1 = interaction-region (node) kernel, 2 = face kernel,
+ * 3 = AMG smoothing product, 4 = stream triad (no discretization needed). */
 enum { PFV_KERNEL_SPMV_A = 0, PFV_KERNEL_NODE = 1, PFV_KERNEL_FACE = 2,
-       PFV_KERNEL_AMG_SMOOTH = 3 /* finest-level smoothing product of the AMG cycle (needs a built hierarchy) */ };
+       PFV_KERNEL_AMG_SMOOTH = 3, /* finest-level smoothing product of the AMG cycle (needs a built hierarchy) */
+       PFV_KERNEL_TRIAD = 4       /* a = b + s c on 3 x 2^27 doubles (3.2 GB moved per launch): the measured
+                                     device bandwidth next to the data-sheet 8 TB/s (SURVEY 8(d) "Metric") */ };
 pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms);
 
 /* Test hook: copy the leading `count` entries of an internal FP64 device array to the host (0 = the

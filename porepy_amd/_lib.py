@@ -38,6 +38,7 @@ EXPORTS = [
     "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
     "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces", "pfv_solve_sharded", "pfv_tpfa_transmissibility_ad",
+    "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
 ]
 
 
@@ -53,7 +54,8 @@ class Stats(C.Structure):
                 ("num_sub_half_faces", C.c_int64), ("sum_block_sq", C.c_int64),
                 ("max_block", C.c_int64), ("amg_setup_ms", C.c_double),
                 ("amg_operator_complexity", C.c_double), ("amg_levels", C.c_int64),
-                ("amg_coarsest_rows", C.c_int64), ("discretize_ms", C.c_double), ("solve_renumbered", C.c_int64)]
+                ("amg_coarsest_rows", C.c_int64), ("discretize_ms", C.c_double), ("solve_renumbered", C.c_int64),
+                ("node_flops", C.c_double), ("node_table_doubles", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -157,6 +159,12 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_get_stats.restype = C.c_int
     lib.pfv_time_kernel.argtypes = [_h, C.c_int, C.c_int, _dp]
     lib.pfv_time_kernel.restype = C.c_int
+    lib.pfv_device_memory.argtypes = [_h, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.pfv_device_memory.restype = C.c_int
+    lib.pfv_active_size.argtypes = [_h, C.POINTER(C.c_int64)]
+    lib.pfv_active_size.restype = C.c_int
+    lib.pfv_get_matrix_rows.argtypes = [_h, C.c_int, C.c_int64, _ip, _ip, _ip, _dp]
+    lib.pfv_get_matrix_rows.restype = C.c_int
     lib.pfv_debug_copy.argtypes = [_h, C.c_int, _dp, C.c_int64]
     lib.pfv_debug_copy.restype = C.c_int
     lib.pfv_spmv_device_rows.argtypes = [_h, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
@@ -229,6 +237,14 @@ class Context:
         self._discretized = False  # a complete MPFA discretization is resident on the device
         self._discretized_m = False  # ... MPSA
         self._discretized_b = False  # ... Biot coupling terms
+        self._lazy_refs: list = []   # weak references to LazyCsr proxies of this handle's matrices (lazy.py)
+
+    def _before_overwrite(self):
+        """Matrices are about to be recomputed: proxies of the current ones fetch their values first."""
+        if self._lazy_refs:
+            from .lazy import detach_all
+
+            detach_all(self)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -247,6 +263,7 @@ class Context:
 
     # ---- inputs -------------------------------------------------------------------
     def set_grid(self, raw: dict):
+        self._before_overwrite()
         self._discretized = False
         self._discretized_m = False
         self._discretized_b = False
@@ -389,8 +406,30 @@ class Context:
         src = None if source is None else _f64(source)
         self._check(self.lib.pfv_mpsa_assemble(self._h, _ptr(bcv, _dp), _ptr(src, _dp)))
 
-    def active_rhs(self, n):
-        b = np.empty(n, dtype=np.float64)
+    def free_device_bytes(self):
+        """Free HBM of the handle's device in bytes (None from the host-emulation build)."""
+        f, t = C.c_int64(), C.c_int64()
+        self._check(self.lib.pfv_device_memory(self._h, C.byref(f), C.byref(t)))
+        return None if f.value < 0 else int(f.value)
+
+    def active_size(self) -> int:
+        """Unknowns of the system assembled last (what solve / rhs read and write); 0 if none."""
+        n = C.c_int64()
+        self._check(self.lib.pfv_active_size(self._h, C.byref(n)))
+        return int(n.value)
+
+    def _active_n(self, n=None) -> int:
+        """The library's own size of the active system; a caller-supplied n must agree with it (the
+        output buffers are sized from this, never from caller input)."""
+        m = self.active_size()
+        if m <= 0:
+            raise RuntimeError("no assembled system on this handle (assemble / set_system first)")
+        if n is not None and int(n) != m:
+            raise ValueError(f"the assembled system has {m} unknowns, not {int(n)}")
+        return m
+
+    def active_rhs(self, n=None):
+        b = np.empty(self._active_n(n), dtype=np.float64)
         self._check(self.lib.pfv_get_rhs(self._h, _ptr(b, _dp)))
         return b
 
@@ -398,10 +437,12 @@ class Context:
     def discretize(self, rebuild_topology=False, skip_vector_source=False):
         flags = (DISCR_REBUILD_TOPOLOGY if rebuild_topology else 0) | \
                 (DISCR_SKIP_VECTOR_SOURCE if skip_vector_source else 0)
+        self._before_overwrite()
         self._check(self.lib.pfv_mpfa_discretize(self._h, flags))
         self._discretized = True
 
     def tpfa_discretize(self, vector_source_dim: int):
+        self._before_overwrite()
         self._check(self.lib.pfv_tpfa_discretize(self._h, int(vector_source_dim)))
         self._discretized = False
         self._vs_dim = int(vector_source_dim)
@@ -414,6 +455,7 @@ class Context:
         """Recompute the rows of ``faces`` only (partial discretization / update)."""
         fa = np.ascontiguousarray(faces, dtype=np.int32)
         flags = DISCR_SKIP_VECTOR_SOURCE if skip_vector_source else 0
+        self._before_overwrite()
         self._check(self.lib.pfv_mpfa_discretize_faces(self._h, flags, fa.size, _ptr(fa, _ip),
                                                        1 if keep_other_rows else 0))
         self._discretized = self._discretized and bool(keep_other_rows)
@@ -422,6 +464,22 @@ class Context:
         r, c, z = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self.lib.pfv_matrix_info(self._h, which, C.byref(r), C.byref(c), C.byref(z)))
         return r.value, c.value, z.value
+
+    def matrix_rows(self, which: int, rows) -> "sps.csr_matrix":
+        """Rows ``rows`` of a result matrix as a (len(rows) x ncols) scipy csr: gathered on the device, only
+        those entries cross PCIe."""
+        import scipy.sparse as sps
+
+        _, ncols, _ = self.matrix_info(which)
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        indptr = np.empty(rows.size + 1, dtype=np.int32)
+        self._check(self.lib.pfv_get_matrix_rows(self._h, which, rows.size, _ptr(rows, _ip), _ptr(indptr, _ip), None, None))
+        indices = np.empty(max(int(indptr[-1]), 1), dtype=np.int32)
+        data = np.empty(max(int(indptr[-1]), 1), dtype=np.float64)
+        self._check(self.lib.pfv_get_matrix_rows(self._h, which, rows.size, _ptr(rows, _ip), _ptr(indptr, _ip),
+                                                 _ptr(indices, _ip), _ptr(data, _dp)))
+        nnz = int(indptr[-1])
+        return sps.csr_matrix((data[:nnz], indices[:nnz], indptr), shape=(rows.size, ncols))
 
     def matrix(self, which: int, rows=None):
         """Copy a result matrix to the host as scipy csr (int32 sorted indices, FP64).
@@ -502,9 +560,7 @@ class Context:
         return out
 
     def rhs(self):
-        b = np.empty(self.nc, dtype=np.float64)
-        self._check(self.lib.pfv_get_rhs(self._h, _ptr(b, _dp)))
-        return b
+        return self.active_rhs()
 
     def spmv(self, which: int, x):
         nrows, ncols, _ = self.matrix_info(which)
@@ -521,8 +577,10 @@ class Context:
         ``restart``: GMRES cycle length (0 = 30); ``precond``: "jacobi" or "amg"."""
         code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB, "gmres": SOLVE_GMRES}[method]
         self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1}[precond]))
-        x = np.empty(self.nc if n is None else int(n), dtype=np.float64)
+        x = np.empty(self._active_n(n), dtype=np.float64)
         x0a = None if x0 is None else _f64(x0)
+        if x0a is not None and x0a.shape != x.shape:
+            raise ValueError("x0 has the wrong length")
         info = SolveInfo()
         st = self.lib.pfv_solve(self._h, code, float(rtol), int(maxit), int(restart), _ptr(x0a, _dp), _ptr(x, _dp),
                                 C.byref(info))

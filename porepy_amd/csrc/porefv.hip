@@ -391,6 +391,8 @@ pfv_status pfv_tpfa_discretize(pfv_ctx* h, int vector_source_dim) {
     tm.start(s);
     h->have_symbolic = false;  // the MPFA patterns (if any) are replaced
     h->rows_complete = false;
+    for (int m = PFV_MAT_FLUX; m <= PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE; ++m) h->filled[m] = false;
+    h->filled[PFV_MAT_SYSTEM] = false;
     pfv::tpfa_discretize(*h, vector_source_dim);
     h->stats.face_ms = tm.stop(s);
     h->tpfa_mode = true;
@@ -508,6 +510,50 @@ pfv_status pfv_get_matrix(pfv_ctx* h, int which, int32_t* indptr, int32_t* indic
   });
 }
 
+pfv_status pfv_get_matrix_rows(pfv_ctx* h, int which, int64_t n_rows, const int32_t* rows, int32_t* out_indptr,
+                               int32_t* out_indices, double* out_data) {
+  return guarded(h, [&] {
+    require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
+    require(which == PFV_MAT_USER_SYSTEM ? h->filled[which] : (which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic), "discretize first");
+    require(n_rows >= 0 && (n_rows == 0 || rows) && out_indptr, "bad row list");
+    const pfv::CsrPattern& P = h->pattern_of(which);
+    for (int64_t i = 0; i < n_rows; ++i) require(rows[i] >= 0 && rows[i] < P.nrows, "row index out of range");
+    auto s = h->stream;
+    pfv::Buf<int32_t> d_rows, d_len, d_ix;
+    pfv::Buf<int64_t> d_ptr;
+    pfv::Buf<double> d_val;
+    int32_t* dr = d_rows.ensure(std::max<int64_t>(n_rows, 1));
+    int32_t* dl = d_len.ensure(n_rows + 1);
+    int64_t* dp = d_ptr.ensure(n_rows + 1);
+    be_h2d(dr, rows, sizeof(int32_t) * (size_t)n_rows, s);
+    const int32_t* ip = P.indptr;
+    pfv::parallel_for(s, n_rows, PFV_LAMBDA(int64_t i) { dl[i] = ip[dr[i] + 1] - ip[dr[i]]; });
+    pfv::exclusive_scan<int32_t, int64_t>(s, h->scratch, dl, dp, (size_t)n_rows);
+    std::vector<int64_t> hp((size_t)n_rows + 1);
+    be_d2h(hp.data(), dp, sizeof(int64_t) * (size_t)(n_rows + 1), s);
+    require(hp[(size_t)n_rows] < (int64_t(1) << 31), "more than 2^31 entries requested");
+    for (int64_t i = 0; i <= n_rows; ++i) out_indptr[i] = (int32_t)hp[(size_t)i];
+    if (!out_indices && !out_data) return;
+    require(!out_data || h->filled[which], "matrix values have not been computed");
+    const int64_t tot = hp[(size_t)n_rows];
+    const int32_t* ix = P.indices;
+    const double* val = out_data ? h->val[which].p : nullptr;
+    int32_t* tix = d_ix.ensure(std::max<int64_t>(tot, 1));
+    double* tv = d_val.ensure(std::max<int64_t>(out_data ? tot : 1, 1));
+    pfv::wave_for<16>(s, n_rows, 0, PFV_LAMBDA(const pfv::WaveCtx& w) {
+      const int64_t i = w.item;
+      const int p0 = ip[dr[i]], len = dl[i];
+      const int64_t o = dp[i];
+      PFV_LANES(k, len) {
+        tix[o + k] = ix[p0 + k];
+        if (val) tv[o + k] = val[p0 + k];
+      }
+    });
+    if (out_indices) be_d2h(out_indices, tix, sizeof(int32_t) * (size_t)tot, s);
+    if (out_data) be_d2h(out_data, tv, sizeof(double) * (size_t)tot, s);
+  });
+}
+
 pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* vector_source,
                              const double* source) {
   return guarded(h, [&] {
@@ -530,6 +576,7 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     if (!h->have_system) {
       pfv::assemble_system(*h);
       if (h->amg) h->amg->valid = false;
+      if (h->amg_block) h->amg_block->valid = false;
       h->perm_for_val = nullptr;
       // windows built for this very pattern by the discretize call are kept
       if (h->win_rows_prebuilt) h->win_rows_prebuilt = false;
@@ -834,6 +881,7 @@ pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     if (!h->have_mech_system) {
       pfv::mpsa_assemble_system(*h);
       if (h->amg) h->amg->valid = false;
+      if (h->amg_block) h->amg_block->valid = false;
       h->perm_for_val = nullptr;
       h->win_for = h->win_rows_for = nullptr;
     }
@@ -848,6 +896,27 @@ pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     h->active_bs = h->nd;
     h->active_is_grid = true;
     h->active.valid = true;
+  });
+}
+
+pfv_status pfv_device_memory(pfv_ctx* h, int64_t* free_bytes, int64_t* total_bytes) {
+  return guarded(h, [&] {
+    require(free_bytes && total_bytes, "null output");
+#ifdef PFV_EMULATE
+    *free_bytes = *total_bytes = -1;  // host emulation: unknown
+#else
+    size_t f = 0, t = 0;
+    PFV_HIP_CHECK(hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f + (int64_t)h->pool.cached;  // blocks parked in the handle's cache are reusable
+    *total_bytes = (int64_t)t;
+#endif
+  });
+}
+
+pfv_status pfv_active_size(pfv_ctx* h, int64_t* n) {
+  return guarded(h, [&] {
+    require(n != nullptr, "null output");
+    *n = h->active.valid ? h->active.n : 0;
   });
 }
 
@@ -1016,6 +1085,7 @@ pfv_status pfv_set_system(pfv_ctx* h, int64_t n, const int32_t* indptr, const in
     h->active.n = n;
     h->active_bs = 1;
     if (h->amg) h->amg->valid = false;
+    if (h->amg_block) h->amg_block->valid = false;
     h->perm_for_val = nullptr;
     h->win_for = h->win_rows_for = nullptr;
     h->active_is_grid = false;
@@ -1300,6 +1370,29 @@ pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms) {
       pfv::amg_spmv(*h, *amg, L, x, y, b);
       tm.start(s);
       for (int i = 0; i < reps; ++i) pfv::amg_spmv(*h, *amg, L, x, y, b);
+      *avg_ms = tm.stop(s) / reps;
+    } else if (kernel == PFV_KERNEL_TRIAD) {
+      const size_t n = size_t(1) << 27;
+      pfv::Buf<double> buf;
+      double* a = buf.ensure(3 * n);
+      double* b = a + n;
+      double* cc = b + n;
+      pfv::be_memset(a, 0, 3 * n * sizeof(double), s);
+      pfv::D2* a2 = reinterpret_cast<pfv::D2*>(a);
+      const pfv::D2* b2 = reinterpret_cast<const pfv::D2*>(b);
+      const pfv::D2* c2 = reinterpret_cast<const pfv::D2*>(cc);
+      auto triad = [&] {  // 16 bytes per lane and stream
+        pfv::parallel_for(s, (int64_t)(n / 2), PFV_LAMBDA(int64_t i) {
+          const pfv::D2 x = b2[i], y = c2[i];
+          pfv::D2 r;
+          r.x = x.x + 0.5 * y.x;
+          r.y = x.y + 0.5 * y.y;
+          a2[i] = r;
+        });
+      };
+      triad();
+      tm.start(s);
+      for (int i = 0; i < reps; ++i) triad();
       *avg_ms = tm.stop(s) / reps;
     } else if (kernel == PFV_KERNEL_NODE) {
       require(h->have_numeric, "discretize first");

@@ -19,6 +19,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib
+from .lazy import LazyCsr
 from .grid import grid_to_raw
 from .partial import active_indices
 from .periodic import merge_periodic
@@ -93,13 +94,98 @@ def plane_basis(nodes: np.ndarray, tol: float = 1e-5):
     return np.ascontiguousarray(v[:, [2, 1]].T)
 
 
+def grid_fingerprint(sd) -> tuple:
+    """Cheap digest of what `_upload_grid` reads from ``sd``: sizes, a strided checksum of the node and
+    face-centre coordinates, and the periodic map.  Not cryptographic -- it catches the cases the
+    reference handles by re-reading ``sd`` in every call (moved nodes + compute_geometry, a periodic map
+    set or cleared after the first discretize)."""
+    nodes = np.asarray(sd.nodes)
+    fc = np.asarray(sd.face_centers)
+    step_n = max(1, nodes.shape[1] // 4096)
+    step_f = max(1, fc.shape[1] // 4096)
+    per = getattr(sd, "periodic_face_map", None)
+    per_key = None if per is None else (np.asarray(per).shape, int(np.asarray(per).sum()))
+    return (sd.num_cells, sd.num_faces, sd.num_nodes, float(nodes[:, ::step_n].sum()), float(nodes.sum()),
+            float(fc[:, ::step_f].sum()), float(np.asarray(sd.face_areas).sum()), per_key)
+
+
+_IGNORED_NOTED: set = set()
+
+
+def note_ignored_parameters(pd: dict, keyword: str) -> None:
+    """Keys the reference's Mpfa reads (mpfa.py:119-167) that have no effect here: say so once per key."""
+    import logging
+
+    notes = {
+        "mpfa_inverter": "the local systems are inverted by the device kernel (register Gauss-Jordan); "
+                         "the reference's numba / python / cython choice does not apply",
+        "reconstruction_eta": "pressure traces are reconstructed at the continuity points of `mpfa_eta`, "
+                              "as the reference does when the key is absent",
+    }
+    for key, why in notes.items():
+        if key in pd and (keyword, key) not in _IGNORED_NOTED:
+            _IGNORED_NOTED.add((keyword, key))
+            logging.getLogger("porepy_amd").warning("parameter %r of %r is ignored: %s", key, keyword, why)
+
+
+def estimate_device_bytes(sd) -> int:
+    """Upper estimate of the HBM one MPFA handle needs for ``sd`` (the reference estimates its peak memory
+    to choose a sub-problem count, mpfa.py:1315-1355): grid, sub-cell topology, per-node response tables,
+    the four CSR patterns with their value arrays, and the transient work space of the symbolic phase."""
+    nd = sd.dim
+    nc, nf = sd.num_cells, sd.num_faces
+    nsf = sps_nnz(sd.face_nodes)                     # sub-faces
+    fpc = sps_nnz(sd.cell_faces) / max(nc, 1)        # faces per cell
+    npf = nsf / max(nf, 1)                           # nodes per face
+    nh = sps_nnz(sd.cell_faces) * npf                # sub-half-faces
+    nn = sd.num_nodes
+    deg = nh / nd / max(nn, 1)                       # cells per node
+    n_loc = nsf / max(nn, 1)                         # sub-faces per node
+    row = npf * deg * 0.8                            # flux row length (structural stencil, shared cells merged)
+    nnz_flux = nf * row
+    nnz_A = nc * min(fpc * row * 0.35, nc)
+    tables = 8 * nn * (n_loc + 1) * (nd * deg + 1)
+    patterns = 4 * (nnz_flux * (1 + nd) + nnz_A) + 3 * nnz_flux
+    values = 8 * (2 * nnz_flux * (1 + nd) + nnz_A) + 8 * 2 * 0.05 * nnz_flux
+    topo = 12 * nh + 64 * nsf + 32 * nf + 40 * nn
+    grid = 8 * (3 * nn + 3 * nc + 7 * nf) + 9 * 8 * nc + 5 * (sps_nnz(sd.cell_faces) + nsf)
+    staging = nf * npf * deg * (4 + npf) + 4 * nc * fpc * npf * deg
+    solver = 12 * nnz_A * 2.3 + 8 * nc * 24
+    return int(1.15 * (tables + patterns + values + topo + grid + staging + solver))
+
+
+def check_device_memory(ctx, sd, partition_arguments=None) -> None:
+    """`partition_arguments` (mpfa.py:160-161, 246-372) bounds the reference's peak host memory by
+    discretizing overlapping sub-grids one after another.  On the device the footprint is known before
+    anything is allocated; the discretization is done in one piece if it fits the free HBM and refused with
+    the numbers otherwise -- a multi-GPU node shards it (distributed.ShardedMpfa), and rows can be pulled
+    patch by patch (`Context.matrix_rows`, `LazyCsr`) instead of as whole matrices."""
+    import logging
+
+    need = estimate_device_bytes(sd)
+    free = ctx.free_device_bytes()
+    if partition_arguments:
+        logging.getLogger("porepy_amd").info(
+            "partition_arguments=%r: the grid is discretized in one piece on the device (estimated %.1f GB of "
+            "%.1f GB free); the key only bounds host memory in the reference", partition_arguments,
+            need / 1e9, (free or 0) / 1e9)
+    if free is not None and need > free:
+        raise MemoryError(
+            f"MPFA on this grid needs about {need / 1e9:.1f} GB of device memory, {free / 1e9:.1f} GB are free "
+            f"({sd.num_cells} cells; a 288 GB MI355X holds about 14 M tetrahedra per handle). Shard the grid over "
+            "several GPUs (porepy_amd.distributed.ShardedMpfa) or discretize it in pieces with "
+            "specified_cells / specified_faces.")
+
+
 class Mpfa:
     """MPFA-O flux discretization for ``keyword`` on the device."""
 
-    def __init__(self, keyword: str, device: int = 0, library=None):
+    def __init__(self, keyword: str, device: int = 0, library=None, lazy: bool = False):
         self.keyword = keyword
         self.device = device
         self._library = library  # None -> the gfx950 product library
+        # lazy: data[DISCRETIZATION_MATRICES][kw] holds LazyCsr proxies (lazy.py) instead of host copies
+        self.lazy = bool(lazy)
         self.flux_matrix_key = "flux"
         self.bound_flux_matrix_key = "bound_flux"
         self.bound_pressure_cell_matrix_key = "bound_pressure_cell"
@@ -107,6 +193,7 @@ class Mpfa:
         self.vector_source_matrix_key = "vector_source"
         self.bound_pressure_vector_source_matrix_key = "bound_pressure_vector_source"
         self._contexts: dict = {}
+        self._fingerprints: dict = {}  # id(sd) -> cheap digest of the uploaded geometry / topology
         self._tpfa_discr = None  # grids of dimension < 2
         self._plane: dict = {}  # id(sd) -> (2, 3) in-plane basis of a tilted 2-D grid, or None
         self._periodic: dict = {}  # id(sd) -> PeriodicMerge of a grid with periodic faces, or None
@@ -123,8 +210,22 @@ class Mpfa:
             ctx = _lib.Context(self.device, self._library)
             self._upload_grid(ctx, sd)
             self._contexts[key] = (sd, ctx)
+            self._fingerprints[key] = grid_fingerprint(sd)
             return ctx
+        # the reference reads sd afresh in every discretize call: if the caller moved nodes, recomputed
+        # the geometry or (un)set a periodic map since the upload, upload again
+        fp = grid_fingerprint(sd)
+        if fp != self._fingerprints.get(key):
+            self._upload_grid(ent[1], sd)
+            self._fingerprints[key] = fp
         return ent[1]
+
+    def invalidate(self, sd=None) -> None:
+        """Forget the device copy of ``sd`` (all grids if None); the next call uploads it again."""
+        keys = list(self._contexts) if sd is None else [id(sd)]
+        for k in keys:
+            self._contexts.pop(k, None)
+            self._fingerprints.pop(k, None)
 
     def _upload_grid(self, ctx, sd):
         raw = grid_to_raw(sd)
@@ -190,7 +291,10 @@ class Mpfa:
         elif np.asarray(eta).size != 1:
             eta_sub = np.asarray(eta, dtype=float)
             eta = 0.0
+        note_ignored_parameters(pd, self.keyword)
         ctx = self.context(sd)
+        if not ctx.has_discretization:  # (a handle that already holds this grid's discretization reuses its buffers)
+            check_device_memory(ctx, sd, pd.get("partition_arguments"))
         T = self._plane.get(id(sd))
         merge = self._periodic.get(id(sd))
         if merge is not None and (partial or update or subface):
@@ -242,7 +346,11 @@ class Mpfa:
 
             basis = T if T is not None else np.eye(2, 3)
             lift = sps.kron(sps.identity(sd.num_cells, format="csr"), sps.csr_matrix(basis), format="csr")
+        simple = merge is None and lift is None and order is None and rows is None and not (partial and update)
         for name, which in _KEYS:
+            if self.lazy and simple:
+                md[name] = LazyCsr(ctx, which)
+                continue
             new = ctx.matrix(which, rows=rows)
             if merge is not None:
                 new = merge.copy_rows(new, trace=name.startswith("bound_pressure"))

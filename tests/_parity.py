@@ -832,6 +832,185 @@ def full_size_patch_parity(lib, n_side: int = 69, seeds=(0, None, -1)):
     return {"iterations": info["iterations"], "rows_checked": checked}
 
 
+class PatchCutter:
+    """Cuts patches (some cells + one node-ring of halo cells) out of a raw grid, with the incidence
+    products of the full grid built once (distributed.extract_subdomain rebuilds them per call)."""
+
+    def __init__(self, raw: dict):
+        import scipy.sparse as sps
+
+        self.raw = raw
+        nc = raw["cell_centers"].shape[1]
+        nf = raw["face_centers"].shape[1]
+        nn = raw["nodes"].shape[1]
+        self.nc, self.nf, self.nn = nc, nf, nn
+        self.cf = sps.csc_matrix((np.ones(raw["cf_indices"].size, dtype=np.int8), raw["cf_indices"], raw["cf_indptr"]),
+                                 shape=(nf, nc))
+        self.fn = sps.csc_matrix((np.ones(raw["fn_indices"].size, dtype=np.int8), raw["fn_indices"], raw["fn_indptr"]),
+                                 shape=(nn, nf))
+        self.gsign = sps.csc_matrix((raw["cf_sign"].astype(np.int8), raw["cf_indices"], raw["cf_indptr"]), shape=(nf, nc))
+        self.cell_nodes = (self.fn.astype(np.int32) @ self.cf.astype(np.int32)).tocsc()  # nn x nc
+        self.node_cells = self.cell_nodes.tocsr()
+        self.sides = np.bincount(raw["cf_indices"], minlength=nf)
+
+    def cells_around(self, c0: int) -> np.ndarray:
+        cn = self.cell_nodes
+        return np.unique(self.node_cells[cn.indices[cn.indptr[c0]: cn.indptr[c0 + 1]]].indices)
+
+    def cut(self, own: np.ndarray):
+        import scipy.sparse as sps
+
+        raw = self.raw
+        own = np.asarray(own)
+        own_nodes = np.unique(self.cell_nodes[:, own].indices)
+        ring = np.unique(self.node_cells[own_nodes].indices)
+        halo = np.setdiff1d(ring, own)
+        cells = np.concatenate([own, halo])
+        faces = np.unique(self.cf[:, cells].indices)
+        nodes = np.unique(self.fn[:, faces].indices)
+        fmap = np.full(self.nf, -1, dtype=np.int64)
+        fmap[faces] = np.arange(faces.size)
+        nmap = np.full(self.nn, -1, dtype=np.int64)
+        nmap[nodes] = np.arange(nodes.size)
+        loc_cf = self.gsign[:, cells].tocsc()
+        loc_cf = sps.csc_matrix((loc_cf.data, fmap[loc_cf.indices], loc_cf.indptr), shape=(faces.size, cells.size))
+        loc_cf.sort_indices()
+        loc_fn = self.fn[:, faces].tocsc()
+        loc_fn = sps.csc_matrix((loc_fn.data, nmap[loc_fn.indices], loc_fn.indptr), shape=(nodes.size, faces.size))
+        loc_fn.sort_indices()
+        sides_loc = np.bincount(loc_cf.indices, minlength=faces.size)
+        lraw = {
+            "dim": raw["dim"], "name": raw.get("name", ""),
+            "nodes": np.ascontiguousarray(raw["nodes"][:, nodes]),
+            "cf_indptr": loc_cf.indptr.astype(np.int32), "cf_indices": loc_cf.indices.astype(np.int32),
+            "cf_sign": loc_cf.data.astype(np.int8),
+            "fn_indptr": loc_fn.indptr.astype(np.int32), "fn_indices": loc_fn.indices.astype(np.int32),
+            "face_normals": np.ascontiguousarray(raw["face_normals"][:, faces]),
+            "face_centers": np.ascontiguousarray(raw["face_centers"][:, faces]),
+            "cell_centers": np.ascontiguousarray(raw["cell_centers"][:, cells]),
+            "face_areas": np.ascontiguousarray(raw["face_areas"][faces]),
+            "cell_volumes": np.ascontiguousarray(raw["cell_volumes"][cells]),
+        }
+        art = (sides_loc == 1) & (self.sides[faces] == 2)
+        return lraw, own.size, cells.astype(np.int64), faces.astype(np.int64), art
+
+
+def patch_targets(raw: dict, n_random: int = 6, seed: int = 3):
+    """Cells to centre patches on: the 8 corners of the bounding box, the centres of its 6 sides (where the
+    Dirichlet / Neumann faces and their edges are) and n_random cells anywhere."""
+    cc = raw["cell_centers"]
+    lo, hi = raw["face_centers"].min(axis=1), raw["face_centers"].max(axis=1)
+    pts = []
+    for ix in (0, 1):
+        for iy in (0, 1):
+            for iz in (0, 1):
+                pts.append([(lo, hi)[ix][0], (lo, hi)[iy][1], (lo, hi)[iz][2]])
+    mid = 0.5 * (lo + hi)
+    for d in range(3):
+        for side in (lo, hi):
+            q = mid.copy()
+            q[d] = side[d]
+            pts.append(q)
+    cells = [int(np.argmin(((cc - np.asarray(q)[:, None]) ** 2).sum(axis=0))) for q in pts]
+    rng = np.random.default_rng(seed)
+    cells += [int(c) for c in rng.integers(cc.shape[1], size=n_random)]
+    return cells
+
+
+def grid_patch_parity(lib, raw, Kvals, flags, eta, bv=None, src=None, targets=None, rtol=1e-13, check_solve=True):
+    """Rows of ALL SIX device matrices and of A = div flux of one full-size problem (raw grid, permeability
+    (3,3,Nc), per-face flags 1 = Dirichlet / 2 = Neumann) against the oracle run on patches cut out of it.
+    A face row only involves the interaction regions of the face's nodes, so on a patch = some cells + one
+    node-ring of halo cells the oracle's rows of the faces of the inner cells are the global rows."""
+    nc, nf = raw["cell_centers"].shape[1], raw["face_centers"].shape[1]
+    nd = int(raw["dim"])
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(raw)
+    ctx.set_params(Kvals, flags, None, eta)
+    ctx.discretize(skip_vector_source=False)
+    out = {}
+    if bv is not None:
+        ctx.assemble(bv, None, src)
+    # (rows are fetched patch by patch, pfv_get_matrix_rows: the six matrices of the 2 M-cell grid are 21.6 GB)
+    if bv is not None and check_solve:
+        x, info = ctx.solve("bicgstab", rtol=rtol, maxit=5000, precond="amg", raise_on_fail=False)
+        b = ctx.rhs()
+        out["iterations"] = info["iterations"]
+        out["true_rel_residual"] = float(np.linalg.norm(b - ctx.spmv(pa._lib.MAT_SYSTEM, x)) / np.linalg.norm(b))
+        out["x"] = x
+    cutter = PatchCutter(raw)
+    is_dir = (flags & 1) != 0
+    bc_all = {"is_dir": is_dir, "is_neu": ~is_dir & (cutter.sides == 1), "is_rob": np.zeros(nf, bool),
+              "is_internal": np.zeros(nf, bool), "robin_weight": np.ones(nf)}
+    targets = patch_targets(raw) if targets is None else targets
+    checked, worst = 0, {}
+    ex = lambda idx: (nd * np.asarray(idx)[:, None] + np.arange(nd)[None, :]).ravel()  # noqa: E731
+    for c0 in targets:
+        inner = cutter.cells_around(c0)
+        lraw, n_own, cell_gid, face_gid, art = cutter.cut(inner)
+        lbc = {k: np.asarray(v)[face_gid].copy() for k, v in bc_all.items()}
+        lbc["is_dir"][art] = False
+        lbc["is_neu"][art] = True
+        ora = mo.discretize(lraw, np.ascontiguousarray(Kvals[:, :, cell_gid]), lbc, eta=eta)
+        lfaces = np.unique(lraw["cf_indices"][: lraw["cf_indptr"][n_own]])  # faces of the inner cells
+        gfaces = face_gid[lfaces]
+        cmap = np.full(nc, -1)
+        cmap[cell_gid] = np.arange(cell_gid.size)
+        fmap = np.full(nf, -1)
+        fmap[face_gid] = np.arange(face_gid.size)
+        vmap = np.full(nd * nc, -1)
+        vmap[ex(cell_gid)] = np.arange(nd * cell_gid.size)
+        for k in ALL_KEYS:
+            m = {"flux": cmap, "bound_pressure_cell": cmap, "bound_flux": fmap, "bound_pressure_face": fmap,
+                 "vector_source": vmap, "bound_pressure_vector_source": vmap}[k]
+            G = ctx.matrix_rows(WHICH[k], gfaces).tocoo()
+            assert np.all(m[G.col] >= 0), (k, c0)  # the global rows stay inside the patch
+            Gl = sps_csr((G.data, (G.row, m[G.col])), shape=(gfaces.size, ora[k].shape[1]))
+            err = rel_max_err(Gl, ora[k][lfaces])
+            worst[k] = max(worst.get(k, 0.0), err)
+            assert err < TOL, (k, c0, err)
+        if bv is not None:
+            Aora, _ = mo.assemble_matrix_rhs(lraw, ora, np.zeros(face_gid.size))
+            G = ctx.matrix_rows(pa._lib.MAT_SYSTEM, cell_gid[:n_own]).tocoo()
+            assert np.all(cmap[G.col] >= 0)
+            Gl = sps_csr((G.data, (G.row, cmap[G.col])), shape=(n_own, cell_gid.size))
+            err = rel_max_err(Gl, Aora[:n_own])
+            worst["A"] = max(worst.get("A", 0.0), err)
+            assert err < TOL, ("A", c0, err)
+        checked += lfaces.size
+    out.update({"rows_checked": checked, "patches": len(targets), "worst_rel_err": worst})
+    return out
+
+
+def bench_grid_patch_parity(lib, n_side: int = 69, n_random: int = 6):
+    """The grid bench.py TIMES (make_slab_problem: hash-perturbed nodes, Morton-numbered cells, log-normal
+    full-tensor K, Dirichlet x-faces) at its full size: all six matrices + A on >= 20 patches (box corners,
+    side centres, random cells), the true residual of the rtol = 1e-13 solve."""
+    import bench
+
+    lp, Kvals, flags, bv, src, eta = bench.make_slab_problem(n_side, 0, 1)
+    return grid_patch_parity(lib, lp.raw, Kvals, flags, eta, bv, src, patch_targets(lp.raw, n_random))
+
+
+def config_c2_patch_parity(lib, n_side: int = 32, n_random: int = 6):
+    """BASELINE configs[1]: StructuredTetrahedralGrid([32]^3), isotropic K = 1, Dirichlet p = x all round --
+    the case where the reference's stored pattern is value dependent (exact zeros on the unperturbed
+    lattice); values of all six matrices + A on patches, and the exact linear field from the solve."""
+    g = pa.StructuredTetrahedralGrid([n_side] * 3, [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    raw = pa.grid_to_raw(g)
+    nc, nf = g.num_cells, g.num_faces
+    Kvals = pa.SecondOrderTensor(np.ones(nc)).values
+    bf = g.get_all_boundary_faces()
+    flags = np.zeros(nf, dtype=np.uint8)
+    flags[bf] = 1
+    bv = np.zeros(nf)
+    bv[bf] = g.face_centers[0, bf]
+    out = grid_patch_parity(lib, raw, Kvals, flags, 1.0 / 3.0, bv, np.zeros(nc), patch_targets(raw, n_random))
+    out["max_abs_error_vs_exact_linear_field"] = float(np.max(np.abs(out["x"] - g.cell_centers[0])))
+    return out
+
+
 def full_size_patch_parity_mpsa(lib, n_side: int = 44, seeds=(0, None, -1)):
     """The same for the elasticity path at BASELINE configs[3] (511 104 tetrahedra, 1.53 M dofs):
     stress / bound_stress rows of the full problem against the MPSA oracle on patches, the exact

@@ -263,3 +263,13 @@ def test_patch_parity_machinery_small(lib):
     """The full-size GPU test's machinery on a small grid (host emulation)."""
     out = P.full_size_patch_parity(lib, 6, seeds=(0, None))
     assert out["rows_checked"] > 20
+
+
+def test_bench_grid_patch_parity_machinery_small(lib):
+    """The machinery of the full-size GPU tests (all six matrices + A on patches of the grid bench.py times,
+    and of the configs[1] lattice) on small grids (host emulation)."""
+    out = P.bench_grid_patch_parity(lib, 5, n_random=2)
+    assert out["patches"] == 16 and out["rows_checked"] > 200
+    assert out["true_rel_residual"] < 1e-12
+    out = P.config_c2_patch_parity(lib, 4, n_random=2)
+    assert out["max_abs_error_vs_exact_linear_field"] < 1e-10

@@ -292,6 +292,21 @@ def test_full_size_rows_match_oracle_on_patches(lib):
     assert out["rows_checked"] > 100
 
 
+def test_timed_bench_grid_all_matrices_on_patches(lib):
+    """The grid bench.py times (make_slab_problem(69): BASELINE configs[2]) at full size: six matrices + A on
+    20 patches (box corners, side centres, random cells) and the rtol = 1e-13 solve the bench line runs."""
+    out = P.bench_grid_patch_parity(lib, 69)
+    assert out["patches"] >= 20 and out["rows_checked"] > 1500
+    assert out["true_rel_residual"] < 1e-12, out["true_rel_residual"]
+
+
+def test_config_c2_all_matrices_on_patches(lib):
+    """BASELINE configs[1] (196 608 tetrahedra, isotropic): six matrices + A on 20 patches, exact linear field."""
+    out = P.config_c2_patch_parity(lib, 32)
+    assert out["patches"] >= 20 and out["rows_checked"] > 1500
+    assert out["max_abs_error_vs_exact_linear_field"] < 1e-10, out["max_abs_error_vs_exact_linear_field"]
+
+
 @pytest.mark.parametrize("name", ["tpfaad_cart2d_4x3", "tpfaad_tri2d_3x3", "tpfaad_tet3d_2x2x2", "tpfaad_cart2d_tilted_3x2"])
 def test_differentiable_tpfa_matches_reference_ad(lib, name):
     P.check_tpfa_ad_case(lib, name)

@@ -1,0 +1,150 @@
+"""Host-side mirror of the operator API (CPU suite, host-emulation library): lazily fetched matrices,
+re-upload when the grid object changed, the device-memory guard, ignored parameters, buffer sizing."""
+import logging
+
+import numpy as np
+import pytest
+
+import porepy_amd as pa
+from porepy_amd.lazy import LazyCsr
+from tests import _parity as P
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return P.emulation_library()
+
+
+def _problem(n=3, seed=0):
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.1 / n, seed=seed)
+    rng = np.random.default_rng(seed)
+    nc = g.num_cells
+    K = pa.SecondOrderTensor(kxx=1 + rng.random(nc), kyy=2 + rng.random(nc), kzz=0.5 + rng.random(nc),
+                             kxy=0.2 * rng.random(nc))
+    bf = g.get_all_boundary_faces()
+    bc = pa.BoundaryCondition(g, bf, ["dir"] * bf.size)
+    bv = np.zeros(g.num_faces)
+    bv[bf] = g.face_centers[0, bf]
+    return g, K, bc, bv
+
+
+def _data(K, bc, bv, **extra):
+    return pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": bv, **extra})
+
+
+def test_lazy_matrices_equal_eager_ones(lib):
+    g, K, bc, bv = _problem()
+    eager, lazy = _data(K, bc, bv), _data(K, bc, bv)
+    pa.Mpfa("flow", library=lib).discretize(g, eager)
+    d = pa.Mpfa("flow", library=lib, lazy=True)
+    d.discretize(g, lazy)
+    me, ml = eager[pa.DISCRETIZATION_MATRICES]["flow"], lazy[pa.DISCRETIZATION_MATRICES]["flow"]
+    for k in me:
+        assert isinstance(ml[k], LazyCsr) and not ml[k].materialized
+        assert ml[k].shape == me[k].shape and ml[k].nnz == me[k].nnz
+    # row slices and products with a vector stay on the device
+    rows = np.array([0, 5, 7])
+    assert abs(ml["flux"][rows] - me["flux"][rows]).max() == 0
+    x = np.linspace(0, 1, g.num_cells)
+    assert np.allclose(ml["flux"] @ x, me["flux"] @ x, rtol=0, atol=1e-13)
+    assert not ml["flux"].materialized
+    # anything else turns the proxy into the plain matrix, once
+    assert abs(ml["bound_flux"].tocsr() - me["bound_flux"]).max() == 0
+    assert np.array_equal(ml["vector_source"].indices, me["vector_source"].indices)
+    A1, b1 = d.assemble_matrix_rhs(g, lazy)
+    e = pa.Mpfa("flow", library=lib)
+    e.discretize(g, eager)
+    A0, b0 = e.assemble_matrix_rhs(g, eager)
+    assert abs(A1 - A0).max() == 0 and np.array_equal(b1, b0)
+
+
+def test_lazy_proxy_keeps_its_values_across_a_rediscretization(lib):
+    g, K, bc, bv = _problem()
+    data = _data(K, bc, bv)
+    d = pa.Mpfa("flow", library=lib, lazy=True)
+    d.discretize(g, data)
+    old = data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"]
+    ref = pa.Mpfa("flow", library=lib)
+    dref = _data(K, bc, bv)
+    ref.discretize(g, dref)
+    K2 = pa.SecondOrderTensor(kxx=3 * np.ones(g.num_cells))
+    data[pa.PARAMETERS]["flow"]["second_order_tensor"] = K2
+    d.discretize(g, data)  # overwrites the device matrices: `old` must have fetched its values before
+    assert old.materialized
+    assert abs(old.tocsr() - dref[pa.DISCRETIZATION_MATRICES]["flow"]["flux"]).max() == 0
+    new = data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"]
+    assert abs(new.tocsr() - old.tocsr()).max() > 1e-3
+
+
+def test_grid_changes_after_the_first_call_are_seen(lib):
+    g, K, bc, bv = _problem()
+    d = pa.Mpfa("flow", library=lib)
+    data = _data(K, bc, bv)
+    d.discretize(g, data)
+    f0 = data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"].copy()
+    # move the nodes of the same grid object and recompute its geometry (the reference re-reads sd every call)
+    moved = pa.perturb_interior_nodes(g, 0.05, seed=7)
+    g.nodes = moved.nodes
+    g.compute_geometry()
+    d.discretize(g, data)
+    f1 = data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"]
+    fresh = _data(K, bc, bv)
+    pa.Mpfa("flow", library=lib).discretize(g, fresh)
+    assert abs(f1 - fresh[pa.DISCRETIZATION_MATRICES]["flow"]["flux"]).max() == 0
+    assert abs(f1 - f0).max() > 1e-6
+
+
+def test_memory_guard_refuses_before_allocating(lib, monkeypatch):
+    g, K, bc, bv = _problem()
+    need = pa.mpfa.estimate_device_bytes(g)
+    assert 1e5 < need < 1e9
+    monkeypatch.setattr(pa._lib.Context, "free_device_bytes", lambda self: need // 2)
+    with pytest.raises(MemoryError, match="Shard the grid"):
+        pa.Mpfa("flow", library=lib).discretize(g, _data(K, bc, bv))
+    monkeypatch.setattr(pa._lib.Context, "free_device_bytes", lambda self: 10 * need)
+    pa.Mpfa("flow", library=lib).discretize(g, _data(K, bc, bv, partition_arguments={"num_subproblems": 4}))
+
+
+def test_memory_estimate_covers_the_benchmark_grid():
+    """~40 GB for the 2 M-cell grid: the estimate must be of that order, not 4 or 400."""
+    class G:  # sizes of StructuredTetrahedralGrid([69] * 3) without building it
+        dim = 3
+        num_cells, num_faces, num_nodes = 1971054, 3970674, 343000
+
+        class _M:
+            def __init__(self, nnz):
+                self.nnz = nnz
+        cell_faces = _M(4 * 1971054)
+        face_nodes = _M(3 * 3970674)
+    est = pa.mpfa.estimate_device_bytes(G)
+    assert 25e9 < est < 80e9, est
+
+
+def test_ignored_reference_parameters_are_reported_once(lib, caplog):
+    g, K, bc, bv = _problem()
+    pa.mpfa._IGNORED_NOTED.clear()
+    with caplog.at_level(logging.WARNING, logger="porepy_amd"):
+        d = pa.Mpfa("flow", library=lib)
+        d.discretize(g, _data(K, bc, bv, mpfa_inverter="python", reconstruction_eta=0.0))
+        d.discretize(g, _data(K, bc, bv, mpfa_inverter="python"))
+    msgs = [r.getMessage() for r in caplog.records]
+    assert sum("mpfa_inverter" in m for m in msgs) == 1 and sum("reconstruction_eta" in m for m in msgs) == 1
+
+
+def test_solve_buffers_are_sized_by_the_library(lib):
+    g, K, bc, bv = _problem()
+    ctx = pa.Context(0, lib)
+    with pytest.raises(RuntimeError, match="no assembled system"):
+        ctx.rhs()
+    import scipy.sparse as sps
+
+    A = sps.diags([2.0] * 5).tocsr()
+    ctx.set_system(A, np.ones(5))
+    assert ctx.active_size() == 5
+    x, info = ctx.solve("bicgstab", rtol=1e-12)  # no n given: sized from the library, not from nc (= 0 here)
+    assert x.shape == (5,) and np.allclose(x, 0.5)
+    with pytest.raises(ValueError, match="5 unknowns"):
+        ctx.solve("bicgstab", n=7)
+    assert ctx.rhs().shape == (5,)
