@@ -134,7 +134,16 @@ def bench_config_c4(pa, device_index: int, rtol: float, precond: str, steps: int
     cc = g.cell_centers
     E, nu = 2.5, 0.25
     err = float(np.max(np.abs(u.reshape(3, -1, order="F") - np.vstack((nu * cc[0] / E, nu * cc[1] / E, -cc[2] / E)))))
+    # interaction-region kernel of MPSA (n = nd x 36 = 108 unknowns at an interior node): FP64 roofline on the
+    # executed flops, 2 n^3 for the Gauss-Jordan inverse + ~40 % for the products that follow it
+    n_int = (n - 1) ** 3
+    mpsa_flops = n_int * 2.0 * 108 ** 3 * 1.4
+    node_roofline = {"bound": "fp64", "kernel": "mpsa node kernel (256 threads per interaction region, column-split register "
+                     "Gauss-Jordan, n = 108)", "ms_per_launch": st["node_ms"], "flops_per_launch_estimate": mpsa_flops,
+                     "achieved": mpsa_flops / (st["node_ms"] * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                     "frac": mpsa_flops / (st["node_ms"] * 1e-3) / 78.6e12}
     return {"workload": "BASELINE configs[3] on 1 GPU: MPSA elasticity, 511104 tetrahedra, 3 dof/cell, rollers + top traction",
+            "roofline_node_kernel": node_roofline,
             "value": nc / dt, "unit": "cells/s", "ms_per_step": 1e3 * dt, "steps": steps, "dofs": 3 * nc,
             "iterations": info["iterations"], "krylov": "bicgstab+" + precond,
             "max_abs_error_vs_exact_uniaxial_field": err,
@@ -345,9 +354,9 @@ def main():
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the secondary lines for BASELINE configs[1] and configs[3] (profiling runs)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak (default): every GPU owns an n x n x n lattice slab of a box that grows with N; "
-                         "strong: the one-GPU box split into N slabs")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default, what the north-star target is quoted on): the one-GPU box of --n-side "
+                         "split into N slabs; weak: every GPU owns an n x n x n lattice slab of a box that grows with N")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (torch-driven sharded solver) on one GPU, for validation")
     args = ap.parse_args()
@@ -361,7 +370,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # validation hook for boxes with fewer GPUs than ranks (never set by the driver): all ranks share
     # GPU 0 and talk over gloo, which exercises everything of the N > 1 path except RCCL itself
-    share_gpu = os.environ.get("PFV_BENCH_SHARE_GPU", "0") == "1"
+    share_gpu = os.environ.get("PFV_BENCH_SHARE_GPU", "0") in ("1", "rccl")
+    share_rccl = os.environ.get("PFV_BENCH_SHARE_GPU", "0") == "rccl"  # try RCCL itself with both ranks on GPU 0
     if share_gpu:
         local_rank = 0
     if args.gpus != world:
@@ -375,7 +385,7 @@ def main():
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        if share_gpu:
+        if share_gpu and not share_rccl:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -633,6 +643,7 @@ def main():
                        "iterations": info["iterations"], "converged": info["converged"],
                        "true_rel_residual": res_true, "field_error": field,
                        "global_cells": ncells_total,
+                       "transport": (info.get("transport") if isinstance(info, dict) else None),
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} z-slab subdomains (1 lattice layer of halo cells recomputed per cut), assembly "
                        "without collectives, BiCGStab with RCCL point-to-point halo exchange + fused all-reduces"},

@@ -54,7 +54,8 @@ enum {
   PFV_MAT_BOUND_DISPLACEMENT_FACE = 10,
   PFV_MAT_MECH_SYSTEM = 11,
   PFV_MAT_USER_SYSTEM = 12, /* matrix handed over by pfv_set_system */
-  PFV_NUM_MATS = 13
+  PFV_MAT_FLUX_JACOBIAN = 13, /* d flux / d p of pfv_mpfa_ad_flux_system, on the pattern of flux */
+  PFV_NUM_MATS = 14
 };
 
 /* boundary-condition flag bits per face (params/bc.py:68-190: is_dir/is_neu/is_rob/
@@ -135,6 +136,24 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn,
 pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t* bc_flags,
                                const double* robin_weight, double eta,
                                const double* eta_subface);
+
+/* Residual and Jacobian of the flow equation with a pressure-dependent permeability, on the device
+ * (csrc/ad_flux.inc; the reference: AdTpfaFlux.diffusive_flux with an Mpfa base discretization,
+ * models/constitutive_laws.py:1195-1336, 1580-1721): q = T_MPFA p + t_bnd bc + VS_MPFA g with the
+ * matrices of the last pfv_mpfa_discretize (computed for K = K(p)), and the product rule
+ * dq = T_MPFA dp + diag(w) dT_TPFA with the two-point derivative of the transmissibility.
+ *   p         cell pressures (Nc)
+ *   dk_dp     d K_rs(c) / d p_c, layout (3,3,Nc) like the permeability (NULL: K does not depend on p)
+ *   bc_values per face (Dirichlet value / Neumann flux); vector_source nd per cell or NULL; source Nc or NULL
+ *   flux_out  Nf values of q, or NULL
+ * Leaves J = d(div q)/dp (pattern of PFV_MAT_SYSTEM) and -(div q - source) as the active system: pfv_solve
+ * then returns the Newton increment; pfv_get_matrix(PFV_MAT_SYSTEM) / pfv_get_rhs copy them out.  With
+ * PFV_AD_WANT_FLUX_JACOBIAN also dq/dp as PFV_MAT_FLUX_JACOBIAN (pattern of flux).  Vectors are host or
+ * device memory as selected by pfv_set_vectors_on_device. */
+#define PFV_AD_WANT_FLUX_JACOBIAN 1u
+pfv_status pfv_mpfa_ad_flux_system(pfv_ctx* h, const double* p, const double* dk_dp, const double* bc_values,
+                                   const double* vector_source, const double* source, double* flux_out,
+                                   uint32_t flags);
 
 /* Boundary conditions given per SUB-FACE (numerics/fv/mpfa.py:761-768): flags and Robin weights with
  * one entry per (face, node) pair in face_nodes CSC order (sorted indices), replacing the per-face
@@ -354,6 +373,23 @@ typedef struct {
 pfv_status pfv_solve_sharded(pfv_ctx* h, int method, double rtol, int maxit, int64_t n_own,
                              const pfv_shard_hooks* hooks, double* d_work, double* d_x_owned,
                              pfv_solve_info* info);
+
+/* The two hooks served natively over RCCL (xGMI), no Python in the iteration (csrc/rccl_hooks.inc):
+ * pack kernel -> ncclGroupStart / ncclSend + ncclRecv per neighbour / ncclGroupEnd -> unpack kernel, and
+ * ncclAllReduce of the fused pair of sums, all enqueued on the handle's stream.  librccl is bound with
+ * dlopen at the first call.  Rank 0 creates the id, the caller distributes its 128 bytes (torch.distributed,
+ * MPI, a file), every rank creates its communicator on its handle's device and describes its halo plan;
+ * pfv_rccl_hooks then fills the struct pfv_solve_sharded takes.  PFV_ERR_UNSUPPORTED from the host-emulation
+ * build or when librccl cannot be loaded. */
+typedef struct pfv_rccl_comm pfv_rccl_comm;
+pfv_status pfv_rccl_unique_id(char* id128);
+pfv_status pfv_rccl_comm_create(pfv_ctx* h, const char* id128, int rank, int world, pfv_rccl_comm** out);
+pfv_status pfv_rccl_set_halo_plan(pfv_rccl_comm* c, int n_peers, const int32_t* peers, const int64_t* send_ptr,
+                                  const int32_t* send_idx, const int64_t* recv_ptr, const int32_t* recv_pos);
+pfv_status pfv_rccl_hooks(pfv_rccl_comm* c, pfv_shard_hooks* out);
+pfv_status pfv_rccl_stats(pfv_rccl_comm* c, int64_t* exchanges, int64_t* allreduces, int64_t* bytes_per_exchange);
+const char* pfv_rccl_last_error(pfv_rccl_comm* c);
+void pfv_rccl_comm_destroy(pfv_rccl_comm* c);
 
 /* run this handle's work on an externally owned HIP stream (hipStream_t passed as void*, e.g.
  * torch.cuda.current_stream().cuda_stream) so that it is ordered with the caller's kernels and

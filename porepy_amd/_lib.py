@@ -19,6 +19,7 @@ MAT_FLUX, MAT_BOUND_FLUX, MAT_BOUND_PRESSURE_CELL, MAT_BOUND_PRESSURE_FACE = 0, 
 MAT_VECTOR_SOURCE, MAT_BOUND_PRESSURE_VECTOR_SOURCE, MAT_SYSTEM = 4, 5, 6
 MAT_STRESS, MAT_BOUND_STRESS, MAT_BOUND_DISPLACEMENT_CELL, MAT_BOUND_DISPLACEMENT_FACE, MAT_MECH_SYSTEM = 7, 8, 9, 10, 11
 MAT_USER_SYSTEM = 12
+MAT_FLUX_JACOBIAN = 13
 BC_DIR, BC_NEU, BC_ROB, BC_INTERNAL = 1, 2, 4, 8
 SOLVE_CG, SOLVE_BICGSTAB, SOLVE_GMRES = 0, 1, 2
 DISCR_REBUILD_TOPOLOGY, DISCR_SKIP_VECTOR_SOURCE = 1, 2
@@ -39,6 +40,8 @@ EXPORTS = [
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
     "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces", "pfv_solve_sharded", "pfv_tpfa_transmissibility_ad",
     "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
+    "pfv_rccl_unique_id", "pfv_rccl_comm_create", "pfv_rccl_set_halo_plan", "pfv_rccl_hooks", "pfv_rccl_stats",
+    "pfv_rccl_last_error", "pfv_rccl_comm_destroy", "pfv_mpfa_ad_flux_system",
 ]
 
 
@@ -159,6 +162,23 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_get_stats.restype = C.c_int
     lib.pfv_time_kernel.argtypes = [_h, C.c_int, C.c_int, _dp]
     lib.pfv_time_kernel.restype = C.c_int
+    lib.pfv_mpfa_ad_flux_system.argtypes = [_h, _dp, _dp, _dp, _dp, _dp, _dp, C.c_uint32]
+    lib.pfv_mpfa_ad_flux_system.restype = C.c_int
+    _i64p = C.POINTER(C.c_int64)
+    lib.pfv_rccl_unique_id.argtypes = [C.c_char_p]
+    lib.pfv_rccl_unique_id.restype = C.c_int
+    lib.pfv_rccl_comm_create.argtypes = [_h, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.pfv_rccl_comm_create.restype = C.c_int
+    lib.pfv_rccl_set_halo_plan.argtypes = [C.c_void_p, C.c_int, _ip, _i64p, _ip, _i64p, _ip]
+    lib.pfv_rccl_set_halo_plan.restype = C.c_int
+    lib.pfv_rccl_hooks.argtypes = [C.c_void_p, C.POINTER(ShardHooks)]
+    lib.pfv_rccl_hooks.restype = C.c_int
+    lib.pfv_rccl_stats.argtypes = [C.c_void_p, _i64p, _i64p, _i64p]
+    lib.pfv_rccl_stats.restype = C.c_int
+    lib.pfv_rccl_last_error.argtypes = [C.c_void_p]
+    lib.pfv_rccl_last_error.restype = C.c_char_p
+    lib.pfv_rccl_comm_destroy.argtypes = [C.c_void_p]
+    lib.pfv_rccl_comm_destroy.restype = None
     lib.pfv_device_memory.argtypes = [_h, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.pfv_device_memory.restype = C.c_int
     lib.pfv_active_size.argtypes = [_h, C.POINTER(C.c_int64)]
@@ -220,6 +240,71 @@ def _f64(a):
 
 def _ptr(a, typ):
     return None if a is None else a.ctypes.data_as(typ)
+
+
+def rccl_unique_id(library=None) -> bytes:
+    """128-byte id of a new RCCL communicator (rank 0 calls this and distributes the bytes)."""
+    lib = library if library is not None else product_library()
+    buf = C.create_string_buffer(128)
+    st = lib.pfv_rccl_unique_id(buf)
+    if st != 0:
+        raise PorefvError(st, "RCCL is not available (gfx950 build with librccl.so needed)")
+    return buf.raw
+
+
+class RcclComm:
+    """Native RCCL transport of a sharded solve (include/porefv.h: pfv_rccl_*): one communicator per rank on
+    the device of ``ctx``, plus this rank's halo plan.  Pass it to ``Context.solve_sharded`` in place of the
+    two Python callables."""
+
+    def __init__(self, ctx: "Context", unique_id: bytes, rank: int, world: int):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self._c = C.c_void_p()
+        st = self.lib.pfv_rccl_comm_create(ctx._h, unique_id, int(rank), int(world), C.byref(self._c))
+        if st != 0:
+            raise PorefvError(st, self.lib.pfv_last_error(ctx._h).decode(errors="replace"))
+        self.rank, self.world = int(rank), int(world)
+
+    def set_halo_plan(self, send: dict, recv: dict):
+        """send[p] = local indices of the owned entries peer p needs (in the order it expects them),
+        recv[p] = positions of the halo entries peer p owns (in the order it sends them)."""
+        peers = sorted(set(send) | set(recv))
+        sp, rp, si, ri = [0], [0], [], []
+        for p in peers:
+            a = np.asarray(send.get(p, []), dtype=np.int32).ravel()
+            b = np.asarray(recv.get(p, []), dtype=np.int32).ravel()
+            si.append(a)
+            ri.append(b)
+            sp.append(sp[-1] + a.size)
+            rp.append(rp[-1] + b.size)
+        pe = np.asarray(peers, dtype=np.int32)
+        spa, rpa = np.asarray(sp, dtype=np.int64), np.asarray(rp, dtype=np.int64)
+        sia = np.concatenate(si).astype(np.int32) if si else np.zeros(0, np.int32)
+        ria = np.concatenate(ri).astype(np.int32) if ri else np.zeros(0, np.int32)
+        st = self.lib.pfv_rccl_set_halo_plan(self._c, len(peers), _ptr(pe, _ip), _ptr(spa, C.POINTER(C.c_int64)),
+                                             _ptr(sia, _ip), _ptr(rpa, C.POINTER(C.c_int64)), _ptr(ria, _ip))
+        if st != 0:
+            raise PorefvError(st, self.lib.pfv_last_error(self.ctx._h).decode(errors="replace"))
+
+    def stats(self) -> dict:
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self.lib.pfv_rccl_stats(self._c, C.byref(a), C.byref(b), C.byref(c))
+        return {"exchanges": a.value, "allreduces": b.value, "bytes_per_exchange": c.value}
+
+    def last_error(self) -> str:
+        return (self.lib.pfv_rccl_last_error(self._c) or b"").decode(errors="replace")
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c:
+            self.lib.pfv_rccl_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -657,17 +742,45 @@ class Context:
                 failure.append(e)
                 return 1
 
-        hooks = ShardHooks(HALO_FN(_halo), ALLREDUCE_FN(_red), None)
+        if isinstance(exchange_halo, RcclComm):
+            # native transport: the hooks are C functions of the library (rccl_hooks.inc), nothing of the
+            # iteration runs in Python
+            hooks = ShardHooks()
+            self._check(self.lib.pfv_rccl_hooks(exchange_halo._c, C.byref(hooks)))
+        else:
+            hooks = ShardHooks(HALO_FN(_halo), ALLREDUCE_FN(_red), None)
         info = SolveInfo()
         st = self.lib.pfv_solve_sharded(self._h, code, float(rtol), int(maxit), int(n_own), C.byref(hooks),
                                         C.c_void_p(work_ptr), C.c_void_p(x_ptr), C.byref(info))
         if failure:
             raise failure[0]
+        if isinstance(exchange_halo, RcclComm) and st not in (0, 6):
+            msg = exchange_halo.last_error()
+            if msg:
+                raise PorefvError(st, "RCCL transport: " + msg)
         out = {"iterations": info.iterations, "converged": bool(info.converged),
                "rel_residual": info.rel_residual, "solve_ms": info.solve_ms}
         if st != 0 and (raise_on_fail or st != 6):
             self._check(st)
         return out
+
+    def ad_flux_system(self, p, dk_dp=None, bc_values=None, vector_source=None, source=None, flux_jacobian=False):
+        """Residual and Jacobian of the flow equation with K = K(p) (pfv_mpfa_ad_flux_system), left on the device
+        as the active system (``solve`` returns the Newton increment; ``matrix(MAT_SYSTEM)`` / ``rhs()`` copy J
+        and -r out).  Returns the face fluxes q; with ``flux_jacobian`` dq/dp is ``matrix(MAT_FLUX_JACOBIAN)``."""
+        pa_ = _f64(p)
+        if pa_.shape != (self.nc,):
+            raise ValueError("p must have one entry per cell")
+        dk = None if dk_dp is None else _f64(dk_dp)
+        if dk is not None and dk.shape != (3, 3, self.nc):
+            raise ValueError("dk_dp must have shape (3, 3, num_cells)")
+        bc = None if bc_values is None else _f64(bc_values)
+        vs = None if vector_source is None else _f64(vector_source)
+        src = None if source is None else _f64(source)
+        q = np.empty(self.nf, dtype=np.float64)
+        self._check(self.lib.pfv_mpfa_ad_flux_system(self._h, _ptr(pa_, _dp), _ptr(dk, _dp), _ptr(bc, _dp), _ptr(vs, _dp),
+                                                     _ptr(src, _dp), _ptr(q, _dp), 1 if flux_jacobian else 0))
+        return q
 
     def tpfa_transmissibility_ad(self, perm):
         """Two-point face transmissibilities and their derivatives with respect to the permeability entries

@@ -158,6 +158,10 @@ inline bool spin_wait_enabled() {
   }();
   return on;
 }
+inline int env_int_early(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
+}
 inline void wait_stream(stream_t s) {
   if (!spin_wait_enabled()) {
     PFV_HIP_CHECK(hipStreamSynchronize(s));
@@ -196,6 +200,41 @@ inline void be_d2h(void* dst, const void* src, size_t bytes, stream_t s) {
     PFV_HIP_CHECK(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, s));
     wait_stream(s);
     std::memcpy(dst, p, bytes);
+    return;
+  }
+  if (bytes >= (size_t(8) << 20) && env_int_early("PFV_PINNED_COPIES", 0) != 0) {
+    // Large results into pageable host memory through two page-locked staging buffers (DMA into one while
+    // the other is copied out).  OFF by default: measured on the MI355X box, the runtime's own pageable
+    // hipMemcpy moves the 1.66 GB system matrix in 70 ms (23 GB/s), this pipeline in 167 ms (bound by the
+    // single-threaded memcpy out of the staging buffer).  Kept as a switch for hosts where that differs.
+    constexpr size_t kChunk = size_t(16) << 20;
+    thread_local char* stage[2] = {nullptr, nullptr};
+    thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i) {
+      if (!stage[i]) {
+        PFV_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&stage[i]), kChunk, hipHostMallocDefault));
+        PFV_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+      }
+    }
+    const char* sp = static_cast<const char*>(src);
+    char* dp = static_cast<char*>(dst);
+    const size_t nchunk = (bytes + kChunk - 1) / kChunk;
+    auto issue = [&](size_t k) {
+      const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
+      PFV_HIP_CHECK(hipMemcpyAsync(stage[k & 1], sp + off, len, hipMemcpyDeviceToHost, s));
+      PFV_HIP_CHECK(hipEventRecord(ev[k & 1], s));
+    };
+    issue(0);
+    for (size_t k = 0; k < nchunk; ++k) {
+      if (k + 1 < nchunk) issue(k + 1);
+      for (;;) {
+        const hipError_t e = hipEventQuery(ev[k & 1]);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) PFV_HIP_CHECK(e);
+      }
+      const size_t off = k * kChunk, len = std::min(kChunk, bytes - off);
+      std::memcpy(dp + off, stage[k & 1], len);
+    }
     return;
   }
   PFV_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
@@ -340,6 +379,7 @@ struct WaveCtx {
 #ifdef PFV_EMULATE
   bool lane0() const { return true; }
   void sync() const {}
+  void lsync() const {}
   // index in [lo, hi) of the largest |base[i * stride]| (lowest index on ties)
   int argmax_abs(const double* base, int stride, int lo, int hi, double* best) const {
     double b = -1.0;
@@ -354,6 +394,18 @@ struct WaveCtx {
 #else
   __device__ bool lane0() const { return lane == 0; }
   __device__ void sync() const { __syncthreads(); }
+  // Ordering of LDS traffic only, for work items that live in ONE wavefront (wave_for): LDS operations of
+  // a wavefront execute in order, so all that is needed is that the compiler keeps the order -- no
+  // s_barrier and, unlike __syncthreads(), no vmcnt(0) that would drain the global loads in flight.
+  // Not for data handed from lane to lane through global memory.
+  __device__ void lsync() const {
+    if (width > 64) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
   __device__ int argmax_abs(const double* base, int stride, int lo, int hi, double* best) const {
     double b = -1.0;
     int p = 0x7fffffff;

@@ -239,6 +239,8 @@ struct pfv_ctx_impl {
       case PFV_MAT_FLUX:
       case PFV_MAT_BOUND_PRESSURE_CELL:
         return subface_bc ? pat_sflux : pat_flux;
+      case PFV_MAT_FLUX_JACOBIAN:
+        return pat_flux;
       case PFV_MAT_BOUND_PRESSURE_FACE:
         return subface_bc ? pat_sbound : (tpfa_mode ? pat_bpf : pat_bound);
       case PFV_MAT_BOUND_FLUX:

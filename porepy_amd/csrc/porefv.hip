@@ -13,6 +13,7 @@
 #include "mpsa.inc"
 #include "tpfa.inc"
 #include "biot.inc"
+#include "ad_flux.inc"
 
 namespace pfv {
 pfv_ctx_impl::pfv_ctx_impl() = default;
@@ -46,6 +47,12 @@ pfv_status guarded(pfv_ctx* h, F&& body) {
 
 void require(bool ok, const char* msg) {
   if (!ok) throw Error(PFV_ERR_ARGUMENT, msg);
+}
+
+bool pattern_ready(const pfv_ctx* h, int which) {
+  if (which == PFV_MAT_USER_SYSTEM) return h->filled[which];
+  if (which == PFV_MAT_FLUX_JACOBIAN) return h->have_symbolic;
+  return which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic;
 }
 
 template <class T>
@@ -487,7 +494,7 @@ pfv_status pfv_mpfa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces
 pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
-    require(which == PFV_MAT_USER_SYSTEM ? h->filled[which] : (which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic), "discretize first");
+    require(pattern_ready(h, which), "discretize first");
     const pfv::CsrPattern& P = h->pattern_of(which);
     if (nrows) *nrows = P.nrows;
     if (ncols) *ncols = P.ncols;
@@ -498,7 +505,7 @@ pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols
 pfv_status pfv_get_matrix(pfv_ctx* h, int which, int32_t* indptr, int32_t* indices, double* data) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
-    require(which == PFV_MAT_USER_SYSTEM ? h->filled[which] : (which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic), "discretize first");
+    require(pattern_ready(h, which), "discretize first");
     const pfv::CsrPattern& P = h->pattern_of(which);
     auto s = h->stream;
     if (indptr) be_d2h(indptr, P.indptr.p, sizeof(int32_t) * (size_t)(P.nrows + 1), s);
@@ -514,7 +521,7 @@ pfv_status pfv_get_matrix_rows(pfv_ctx* h, int which, int64_t n_rows, const int3
                                int32_t* out_indices, double* out_data) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
-    require(which == PFV_MAT_USER_SYSTEM ? h->filled[which] : (which >= PFV_MAT_STRESS ? h->have_mpsa_symbolic : h->have_symbolic), "discretize first");
+    require(pattern_ready(h, which), "discretize first");
     require(n_rows >= 0 && (n_rows == 0 || rows) && out_indptr, "bad row list");
     const pfv::CsrPattern& P = h->pattern_of(which);
     for (int64_t i = 0; i < n_rows; ++i) require(rows[i] >= 0 && rows[i] < P.nrows, "row index out of range");
@@ -587,6 +594,56 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     pfv::assemble_rhs(*h, d_bc, d_vs, d_src);
     h->stats.assemble_ms = tm.stop(s);
     h->have_system = true;
+    h->active.P = &h->pat_A;
+    h->active.val = h->val[PFV_MAT_SYSTEM].p;
+    h->active.diag = h->diag.p;
+    h->active.rhs = h->rhs.p;
+    h->active.n = h->nc;
+    h->active_bs = 1;
+    h->active_is_grid = true;
+    h->active.valid = true;
+  });
+}
+
+pfv_status pfv_mpfa_ad_flux_system(pfv_ctx* h, const double* p, const double* dk_dp, const double* bc_values,
+                                   const double* vector_source, const double* source, double* flux_out,
+                                   uint32_t flags) {
+  return guarded(h, [&] {
+    require(h->have_numeric && !h->tpfa_mode, "pfv_mpfa_discretize first");
+    require(!h->subface_bc, "conditions per sub-face are not covered");
+    require(p != nullptr, "p is required");
+    require(!vector_source || h->filled[PFV_MAT_VECTOR_SOURCE], "vector_source matrix was skipped");
+    auto s = h->stream;
+    const size_t nf = (size_t)h->nf, nc = (size_t)h->nc, nvs = (size_t)h->pat_vs.ncols;
+    pfv::Buf<double> in_;
+    double* in = in_.ensure(nc + 9 * nc + nf + nvs + nc + nf);
+    double* d_p = in;
+    double* d_dk = dk_dp ? in + nc : nullptr;
+    double* d_bc = bc_values ? in + 10 * nc : nullptr;
+    double* d_vs = vector_source ? in + 10 * nc + nf : nullptr;
+    double* d_src = source ? in + 10 * nc + nf + nvs : nullptr;
+    double* d_q = in + 11 * nc + nf + nvs;
+    vec_in(h, d_p, p, nc);
+    if (d_dk) vec_in(h, d_dk, dk_dp, 9 * nc);
+    if (d_bc) vec_in(h, d_bc, bc_values, nf);
+    if (d_vs) vec_in(h, d_vs, vector_source, nvs);
+    if (d_src) vec_in(h, d_src, source, nc);
+    pfv::Timer tm;
+    tm.start(s);
+    pfv::ad_flux_system(*h, d_p, d_dk, d_bc, d_vs, d_src, flux_out ? d_q : nullptr,
+                        (flags & PFV_AD_WANT_FLUX_JACOBIAN) != 0);
+    h->stats.assemble_ms = tm.stop(s);
+    if (flux_out) {
+      if (h->vectors_on_device) pfv::be_d2d(flux_out, d_q, nf * sizeof(double), s);
+      else be_d2h(flux_out, d_q, nf * sizeof(double), s);
+    }
+    pfv::be_sync(s);
+    h->have_system = false;  // PFV_MAT_SYSTEM now holds J, not div flux: pfv_mpfa_assemble rebuilds it
+    if (h->amg) h->amg->valid = false;
+    if (h->amg_block) h->amg_block->valid = false;
+    h->perm_for_val = nullptr;
+    h->win_for = h->win_rows_for = nullptr;
+    h->win_sys_prebuilt = h->win_rows_prebuilt = false;
     h->active.P = &h->pat_A;
     h->active.val = h->val[PFV_MAT_SYSTEM].p;
     h->active.diag = h->diag.p;
@@ -1420,3 +1477,5 @@ pfv_status pfv_debug_copy(pfv_ctx* h, int which, double* dst, int64_t count) {
 }
 
 }  // extern "C"
+
+#include "rccl_hooks.inc"

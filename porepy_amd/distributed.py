@@ -420,11 +420,54 @@ class ShardedMpfa:
                     break
         return x, info
 
+    def rccl_transport(self):
+        """Native RCCL transport of this rank (created on first use): the unique id is made by rank 0 and
+        broadcast through the process group, the halo plan is the one of ``HaloPlan`` (same index lists, same
+        order).  None when the group is not RCCL-backed (gloo tests) or the library cannot load librccl."""
+        if getattr(self, "_rccl", None) is not None or getattr(self, "_rccl_failed", False):
+            return self._rccl
+        self._rccl = None
+        dist = self.dist
+        world = dist.get_world_size() if dist is not None else 1
+        rank = dist.get_rank() if dist is not None else 0
+        if self.device.type != "cuda" or (dist is not None and dist.get_backend() != "nccl"):
+            self._rccl_failed = True
+            return None
+        try:
+            ids = [_lib.rccl_unique_id(self.ctx.lib) if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            comm = _lib.RcclComm(self.ctx, ids[0], rank, world)
+            comm.set_halo_plan({p: v.cpu().numpy() for p, v in self.plan.send.items()},
+                               {q: v.cpu().numpy() for q, v in self.plan.recv.items()})
+            self._rccl = comm
+        except _lib.PorefvError:
+            self._rccl_failed = True
+        return self._rccl
+
     def _solve_library(self, method, rtol, maxit, precond):
         torch = self.torch
         n, nloc, dev = self.n_own, self.n_loc, self.device
         if precond not in ("jacobi", "amg"):
             raise ValueError("precond must be 'jacobi' or 'amg'")
+        import os
+
+        native = self.rccl_transport() if os.environ.get("PFV_SHARDED_TRANSPORT", "rccl") == "rccl" else None
+        if native is not None:
+            # the handle keeps its own stream: nothing of torch takes part in the iteration
+            if precond == "amg" and not self._amg_ready:
+                self.ctx.amg_setup(n)
+                self._amg_ready = True
+            work = torch.empty(2 * nloc + 2, dtype=torch.float64, device=dev)
+            x = torch.empty(n, dtype=torch.float64, device=dev)
+            torch.cuda.current_stream(dev).synchronize()  # the buffers exist before the handle's stream uses them
+            info = self.ctx.solve_sharded(n, native, None, work.data_ptr(), x.data_ptr(),
+                                          method=method, rtol=rtol, maxit=maxit, precond=precond)
+            self.ctx.sync()
+            info["halo_bytes_per_exchange"] = self.plan.bytes_per_exchange
+            info["driver"] = "library"
+            info["transport"] = "rccl (native hooks)"
+            return x, info
         self._use_torch_stream()
         if precond == "amg" and not self._amg_ready:
             self.ctx.amg_setup(n)
@@ -455,6 +498,7 @@ class ShardedMpfa:
                                       method=method, rtol=rtol, maxit=maxit, precond=precond)
         info["halo_bytes_per_exchange"] = self.plan.bytes_per_exchange
         info["driver"] = "library"
+        info["transport"] = "torch.distributed hooks"
         return x, info
 
     def owned_system_rows(self):

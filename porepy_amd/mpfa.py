@@ -320,6 +320,12 @@ class Mpfa:
                        float(eta), eta_sub)
         if subface:
             ctx.set_subface_bc(flags_sub, robin_sub)
+        if self.lazy:
+            # proxies of the previous discretization that only `data` still refers to are dropped, not fetched
+            # (a proxy the caller holds elsewhere stays alive and fetches its values before they are overwritten)
+            for name, _ in _KEYS:
+                if isinstance(md.get(name), LazyCsr):
+                    del md[name]
         rows = None
         try:
             if partial:
@@ -419,6 +425,34 @@ class Mpfa:
         ctx = ent[1]
         ctx.assemble(np.asarray(pd["bc_values"], dtype=float), self._vector_source(sd, pd), None)
         return ctx.matrix(_lib.MAT_SYSTEM), ctx.rhs()
+
+    def ad_flux_system(self, sd, data: dict, p, dk_dp=None, source=None, flux_jacobian: bool = False):
+        """Residual and Jacobian of the flow equation for a pressure-dependent permeability, assembled on the
+        device from the discretization of the last ``discretize(sd, data)`` (which must have run with
+        K = K(p)): what the reference evaluates through ``AdTpfaFlux.diffusive_flux`` with an Mpfa base
+        discretization and its forward AD (models/constitutive_laws.py:1195-1336, 1580-1721).  ``dk_dp``:
+        d K_rs(c) / d p_c as a (3, 3, Nc) array.  Returns the face fluxes q; J = d(div q)/dp and
+        -(div q - source) stay on the device as the active system -- ``newton_increment`` solves it there,
+        ``context(sd).matrix(MAT_SYSTEM)`` / ``.rhs()`` copy them out; with ``flux_jacobian`` dq/dp is
+        ``context(sd).matrix(MAT_FLUX_JACOBIAN)``."""
+        if sd.dim < 2:
+            raise NotImplementedError("the differentiable MPFA flux needs a 2-D or 3-D grid")
+        pd = data[PARAMETERS][self.keyword]
+        ent = self._contexts.get(id(sd))
+        if ent is None or ent[0] is not sd or not ent[1].has_discretization:
+            raise RuntimeError("discretize(sd, data) must run on this object before ad_flux_system")
+        if self._plane.get(id(sd)) is not None or self._periodic.get(id(sd)) is not None:
+            raise NotImplementedError("tilted or periodic grids are not covered by the differentiable flux")
+        return ent[1].ad_flux_system(p, dk_dp, np.asarray(pd["bc_values"], dtype=float), self._vector_source(sd, pd),
+                                     source, flux_jacobian=flux_jacobian)
+
+    def newton_increment(self, sd, method: str = "bicgstab", rtol: float = 1e-10, maxit: int = 20000,
+                         precond: str = "amg"):
+        """Solve J dp = -(div q - source) left by ``ad_flux_system`` on the device.  Returns (dp, info)."""
+        ent = self._contexts.get(id(sd))
+        if ent is None or ent[0] is not sd:
+            raise RuntimeError("ad_flux_system(sd, ...) first")
+        return ent[1].solve(method=method, rtol=rtol, maxit=maxit, precond=precond)
 
     def _vector_source(self, sd, pd):
         """Cell-wise vector source in the coordinates the device discretized in."""

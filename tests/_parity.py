@@ -1158,3 +1158,99 @@ def check_tpfa_ad_case(lib, name: str):
     to_ref = np.lexsort((ci, fi))  # the reference's half-face order: face by face
     assert np.array_equal(fi[to_ref], c.hf_face) and np.array_equal(ci[to_ref], c.hf_cell)
     assert np.array_equal(sg[to_ref], c.hf_sign)
+
+
+def check_ad_flux_system(lib, n=3, seed=0, with_vs=True):
+    """pfv_mpfa_ad_flux_system against the numpy restatement of the reference's differentiable MPFA flux
+    (oracle/ad_flux_oracle.py): fluxes, dq/dp, the Jacobian J = d(div q)/dp left as the active system and the
+    residual; then one Newton increment through pfv_solve against the direct solve."""
+    from oracle import ad_flux_oracle as ao
+
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.1 / n, seed=seed)
+    raw = pa.grid_to_raw(g)
+    rng = np.random.default_rng(seed)
+    nc, nf = g.num_cells, g.num_faces
+    p = rng.random(nc)
+    # K(p) = K0 exp(a p): d K / d p = a K
+    a = 0.7
+    base = pa.SecondOrderTensor(kxx=1 + rng.random(nc), kyy=2 + rng.random(nc), kzz=0.5 + rng.random(nc),
+                                kxy=0.2 * rng.random(nc), kyz=0.1 * rng.random(nc)).values
+    K = base * np.exp(a * p)[None, None, :]
+    dk = a * K
+    bf = g.get_all_boundary_faces()
+    fc = g.face_centers
+    dirf = bf[(fc[0, bf] < 1e-9) | (fc[0, bf] > 1 - 1e-9)]
+    flags = np.zeros(nf, dtype=np.uint8)
+    flags[bf] = 2
+    flags[dirf] = 1
+    bv = np.zeros(nf)
+    bv[dirf] = 1.0 + fc[1, dirf]
+    neuf = np.setdiff1d(bf, dirf)
+    bv[neuf] = 0.01 * rng.random(neuf.size)
+    vs = rng.random(3 * nc) if with_vs else None
+    src = 0.1 * rng.random(nc)
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(raw)
+    ctx.set_params(K, flags, None, 1.0 / 3.0)
+    ctx.discretize()
+    mats = {"flux": ctx.matrix(WHICH["flux"]), "vector_source": ctx.matrix(WHICH["vector_source"])}
+    q = ctx.ad_flux_system(p, dk, bv, vs, src, flux_jacobian=True)
+    J = ctx.matrix(pa._lib.MAT_SYSTEM)
+    mr = ctx.rhs()
+    dq = ctx.matrix(pa._lib.MAT_FLUX_JACOBIAN)
+    qo, dqo, Jo, ro = ao.flux_system(raw, mats, K, dk, p, flags, bv, vs, src)
+    assert np.max(np.abs(q - qo)) <= TOL * np.max(np.abs(qo))
+    assert rel_max_err(dq, dqo) < TOL
+    assert rel_max_err(J, Jo) < TOL
+    assert np.max(np.abs(mr + ro)) <= TOL * np.max(np.abs(ro))
+    # finite-difference check of the two-point part of the oracle itself: d t_f / d p
+    x, info = ctx.solve("bicgstab", rtol=1e-13, maxit=2000, precond="jacobi")
+    xo = spla.spsolve(Jo.tocsc(), -ro)
+    assert np.linalg.norm(x - xo) <= 1e-9 * np.linalg.norm(xo)
+    # K independent of p: J is A itself, and the MPFA assembly after it is intact
+    q2 = ctx.ad_flux_system(p, None, bv, vs, src)
+    J2 = ctx.matrix(pa._lib.MAT_SYSTEM)
+    ctx.assemble(bv, vs, src)
+    A = ctx.matrix(pa._lib.MAT_SYSTEM)
+    assert rel_max_err(J2, A) < 1e-14 and np.allclose(q2, q, rtol=0, atol=1e-13 * np.max(np.abs(q)))
+    return {"iterations": info["iterations"], "nnz_J": int(J.nnz)}
+
+
+class AdFluxCase:
+    """tests/golden/adflux_*.npz: darcy_flux (value, Jacobian) of the reference's AdTpfaFlux with an Mpfa base."""
+
+    def __init__(self, name: str):
+        import os
+
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+        self.grid = {k[5:]: (z[k] if z[k].shape else z[k].item()) for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.perm, self.dk_dp, self.p = z["perm"], z["dk_dp"], z["p"]
+        self.bc_flags, self.bc_values, self.vector_source = z["bc_flags"], z["bc_values"], z["vector_source"]
+        if not np.any(self.vector_source):
+            self.vector_source = None
+
+        def csr(key):
+            return sps_csr((z[key + "_data"], z[key + "_indices"], z[key + "_indptr"]), shape=tuple(z[key + "_shape"]))
+        self.ref_flux, self.ref_div_flux = z["ref_flux"], z["ref_div_flux"]
+        self.ref_flux_jac, self.ref_div_flux_jac = csr("ref_flux_jac"), csr("ref_div_flux_jac")
+        self.ref_mpfa_flux, self.ref_mpfa_vs = csr("ref_mpfa_flux"), csr("ref_mpfa_vector_source")
+
+
+def check_ad_flux_case(lib, name: str):
+    """pfv_mpfa_ad_flux_system (MPFA discretization of K(p) on the device + two-point product rule) against
+    the reference's forward AD."""
+    c = AdFluxCase(name)
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(c.grid)
+    eta = pa.determine_eta(pa.grid_from_raw(c.grid))
+    ctx.set_params(c.perm, c.bc_flags, None, eta)
+    ctx.discretize()
+    assert rel_max_err(ctx.matrix(WHICH["flux"]), c.ref_mpfa_flux) < TOL
+    q = ctx.ad_flux_system(c.p, c.dk_dp, c.bc_values, c.vector_source, None, flux_jacobian=True)
+    assert np.max(np.abs(q - c.ref_flux)) <= TOL * np.max(np.abs(c.ref_flux))
+    assert rel_max_err(ctx.matrix(pa._lib.MAT_FLUX_JACOBIAN), c.ref_flux_jac) < TOL
+    assert rel_max_err(ctx.matrix(pa._lib.MAT_SYSTEM), c.ref_div_flux_jac) < TOL
+    assert np.max(np.abs(ctx.rhs() + c.ref_div_flux)) <= TOL * np.max(np.abs(c.ref_div_flux))

@@ -273,3 +273,10 @@ def test_bench_grid_patch_parity_machinery_small(lib):
     assert out["true_rel_residual"] < 1e-12
     out = P.config_c2_patch_parity(lib, 4, n_random=2)
     assert out["max_abs_error_vs_exact_linear_field"] < 1e-10
+
+
+@pytest.mark.parametrize("with_vs", [True, False])
+def test_ad_flux_system_vs_oracle(lib, with_vs):
+    """Residual + Jacobian of the flow equation with K = K(p), assembled on the device (N4)."""
+    out = P.check_ad_flux_system(lib, 3, with_vs=with_vs)
+    assert out["nnz_J"] > 0

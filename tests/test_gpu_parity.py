@@ -310,3 +310,17 @@ def test_config_c2_all_matrices_on_patches(lib):
 @pytest.mark.parametrize("name", ["tpfaad_cart2d_4x3", "tpfaad_tri2d_3x3", "tpfaad_tet3d_2x2x2", "tpfaad_cart2d_tilted_3x2"])
 def test_differentiable_tpfa_matches_reference_ad(lib, name):
     P.check_tpfa_ad_case(lib, name)
+
+
+@pytest.mark.parametrize("with_vs", [True, False])
+def test_ad_flux_system_vs_oracle(lib, with_vs):
+    """Residual + Jacobian of the flow equation with K = K(p), assembled on the device (N4), incl. a Newton
+    increment from the device-resident system."""
+    out = P.check_ad_flux_system(lib, 5, with_vs=with_vs)
+    assert out["nnz_J"] > 0
+
+
+@pytest.mark.parametrize("name", ["adflux_unit_2cells", "adflux_unit_2cells_novs", "adflux_tet3d_2x2x2"])
+def test_ad_flux_system_matches_reference_ad(lib, name):
+    """darcy_flux value + Jacobian and the mass-balance Jacobian of the reference's AdTpfaFlux (Mpfa base)."""
+    P.check_ad_flux_case(lib, name)

@@ -148,3 +148,40 @@ def test_solve_buffers_are_sized_by_the_library(lib):
     with pytest.raises(ValueError, match="5 unknowns"):
         ctx.solve("bicgstab", n=7)
     assert ctx.rhs().shape == (5,)
+
+
+def test_newton_iteration_with_device_resident_jacobian(lib):
+    """Nonlinear flow problem K(p) = K0 exp(a p): Newton with residual + Jacobian assembled and solved on the
+    device (Mpfa.ad_flux_system / newton_increment) converges quadratically-ish to a state whose residual,
+    re-evaluated by the numpy restatement of the reference's formulas, vanishes.  (The Jacobian is the
+    reference's approximation -- two-point derivative of the MPFA transmissibility -- so the iteration is a
+    quasi-Newton one: it contracts by a constant factor per step.)"""
+    from oracle import ad_flux_oracle as ao
+
+    g, K0, bc, bv = _problem(3, seed=3)
+    nc = g.num_cells
+    base = K0.values.copy()
+    a = 0.4
+    src = 0.05 * np.ones(nc) * g.cell_volumes
+    d = pa.Mpfa("flow", library=lib)
+    p = np.zeros(nc)
+    norms = []
+    for it in range(30):
+        Kp = base * np.exp(a * p)[None, None, :]
+        data = _data(type("K", (), {"values": Kp})(), bc, bv)
+        d.discretize(g, data)
+        q = d.ad_flux_system(g, data, p, a * Kp, source=src)
+        mr = d.context(g).rhs()
+        norms.append(float(np.linalg.norm(mr)))
+        if norms[-1] < 1e-10 * norms[0]:
+            break
+        dp, info = d.newton_increment(g, rtol=1e-12, precond="jacobi")
+        p = p + dp
+    assert norms[-1] < 1e-9 * norms[0], norms
+    assert all(b < 0.6 * a_ for a_, b in zip(norms[1:-1], norms[2:])), norms
+    # the converged state against the oracle's residual
+    raw = pa.grid_to_raw(g)
+    mats = {"flux": data[pa.DISCRETIZATION_MATRICES]["flow"]["flux"],
+            "vector_source": data[pa.DISCRETIZATION_MATRICES]["flow"]["vector_source"]}
+    _, _, _, r = ao.flux_system(raw, mats, Kp, a * Kp, p, pa.bc_flags(bc), bv, None, src)
+    assert np.linalg.norm(r) < 1e-9 * norms[0]
