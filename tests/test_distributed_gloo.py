@@ -284,3 +284,53 @@ def test_two_rank_sharded_mpsa(tmp_path, precond):
         assert o["info"]["converged"]
         assert np.linalg.norm(o["x"].reshape(-1, 3) - x_ref[own]) <= 1e-8 * np.linalg.norm(x_ref)
     assert seen.all()
+
+
+def _md_worker(rank, world, port, out, precond):
+    import torch
+    import torch.distributed as dist
+    import scipy.sparse as sps
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "md_jacobian_box_2fractures.npz"))
+        A = sps.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+        n = A.shape[0]
+        # the reference numbers its unknowns grid by grid (3-D matrix cells first, then the fractures, the
+        # intersection line, the mortar fluxes): contiguous blocks = subdomain-wise ownership
+        owner = (np.arange(n) * world) // n
+        sh = D.ShardedCsr(A, z["b"], owner, device="cpu", library=P.emulation_library(), dist=dist)
+        x, info = sh.solve("bicgstab", rtol=1e-13, maxit=5000, precond=precond)
+        xt, info_t = sh.solve("bicgstab", rtol=1e-13, maxit=5000, precond=precond, driver="torch", check_every=1)
+        torch.save({"gid": sh.owned_gid, "x": x.numpy(), "xt": xt.numpy(), "info": info, "info_t": info_t,
+                    "halo": int(sh.n_loc - sh.n_own)}, os.path.join(out, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,precond", [(2, "jacobi"), (3, "jacobi"), (2, "amg")])
+def test_sharded_solve_of_a_mixed_dimensional_jacobian(tmp_path, world, precond):
+    """The coupled Jacobian of the reference's mixed-dimensional flow model (3-D box, two intersecting
+    fractures, their intersection line, mortar fluxes: tests/_dropin_md_script.py --save) sharded by
+    subdomain blocks: halo plan over matrix, fracture and mortar unknowns, library Krylov loop + hooks."""
+    import torch
+    import torch.multiprocessing as mp
+
+    mp.spawn(_md_worker, args=(world, _free_port(), str(tmp_path), precond), nprocs=world, join=True)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "md_jacobian_box_2fractures.npz"))
+    x = np.zeros(z["x"].size)
+    xt = np.zeros(z["x"].size)
+    for r in range(world):
+        d = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"), weights_only=False)
+        assert d["info"]["converged"] and d["info_t"]["converged"] and d["halo"] > 0
+        x[d["gid"]] = d["x"]
+        xt[d["gid"]] = d["xt"]
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla2
+
+    A = sps.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    xo = spla2.spsolve(A.tocsc(), z["b"])
+    assert np.linalg.norm(x - xo) <= 1e-9 * np.linalg.norm(xo)
+    assert np.linalg.norm(xt - xo) <= 1e-9 * np.linalg.norm(xo)

@@ -69,3 +69,23 @@ def test_differentiable_tpfa_transmissibilities_in_the_reference_model():
         m = out[base + "_model"]
         assert m["device_path_calls"] >= 1 and m["flux_jac_nnz"] > 0
         assert max(m["flux_rel_err"], m["flux_jac_rel_err"], m["trace_rel_err"], m["trace_jac_rel_err"]) < 1e-12
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference PorePy not present")
+def test_mixed_dimensional_model_with_rebound_mpfa_and_hip_solver():
+    """The structured stand-in for BASELINE configs[4]: the reference's SinglePhaseFlow on a 3-D box with two
+    intersecting fractures (2-D subdomains, 1-D intersection, mortar grids), pp.Mpfa rebound and the coupled
+    Jacobian solved by the HIP Krylov solver: all unknowns (matrix, fractures, intersection, mortar fluxes)
+    and the Jacobian reproduce the untouched run."""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "oracle", "shim"), REF, ROOT])
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dropin_md_script.py")], env=env, cwd="/tmp",
+                       capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, r.stderr[-2000:]
+    out = json.loads(line[-1][7:])
+    assert out["dims"] == [3, 2, 1] and out["subdomains"] == 4 and out["interfaces"] == 4 and out["mortar_cells"] > 0
+    assert out["device_calls_by_dim"]["3"] >= 1 and out["device_calls_by_dim"]["2"] >= 2
+    assert out["x_rel_err"] < 1e-10 and out["A_rel_err"] < 1e-10
+    assert out["x_rel_err_hip_solver"] < 1e-10 and out["hip_solver_iterations"] > 0
