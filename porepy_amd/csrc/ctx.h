@@ -130,7 +130,10 @@ struct pfv_ctx_impl {
   Buf<uint8_t> node_bls;      //   their local subface index
   Buf<int64_t> node_tptr;     // [nn+1] offset of the node's response table in `tab`: (n + 1) rows of ldt doubles
   Buf<int64_t> node_tbptr;    // [nn+1] offset of the node's boundary columns in `tabb`: 2 x n x nb doubles
-  Buf<uint8_t> flux_colpairs; // [nnz(flux) * max_face_nodes] for every flux column: the (node of face, cell) pair per node, 0xff = none
+  Buf<uint8_t> flux_colpairs; // for every flux column: the (node of face, cell) pair per node of the face, 0xff = none;
+                              // row of face f at f * cp_stride (cp_stride > 0: fixed stride, as the one-pass symbolic
+                              // phase leaves it) or at indptr[f] * max_face_nodes (cp_stride = 0: compact)
+  int64_t cp_stride = 0;
   Buf<uint8_t> node_active;   // [nn] partial discretization: nodes of the requested faces
   Buf<int32_t> face_subset;   // partial discretization: the requested faces
   bool biot_rows_complete = false;  // every row of the coupling terms holds a current value (updates need it)
