@@ -283,3 +283,10 @@ def test_ad_flux_system_vs_oracle(lib, with_vs):
     """Residual + Jacobian of the flow equation with K = K(p), assembled on the device (N4)."""
     out = P.check_ad_flux_system(lib, 3, with_vs=with_vs)
     assert out["nnz_J"] > 0
+
+
+def test_amg_robustness_sweep_small(lib):
+    """The sweep of the GPU suite at a quarter of the size (host emulation)."""
+    out = P.amg_robustness_sweep(lib, scale=0.25)
+    for k, (n, its, res) in out.items():
+        assert res < 1.05e-10 and its <= 40, (k, n, its, res)
