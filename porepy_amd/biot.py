@@ -72,6 +72,11 @@ class Biot(Mpsa):
         ctx.biot_set_alphas(alphas)
         if partial and not alphas:
             return Mpsa.discretize(self, sd, data)
+        if partial and update and not ctx.has_biot_discretization:
+            # an update needs a complete set of coupling terms on the handle (an MPSA-only discretization,
+            # or none, came before): discretize everything -- the rows outside the active set must not
+            # come back as zeros
+            partial = False
         active_cells, active_faces = np.arange(sd.num_cells), np.arange(sd.num_faces)
         try:
             if partial:

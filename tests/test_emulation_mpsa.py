@@ -113,3 +113,35 @@ def test_biot_partial_discretization_and_update(lib, name):
 def test_patch_parity_machinery_small(lib):
     out = P.full_size_patch_parity_mpsa(lib, 4, seeds=(0, None))
     assert out["rows_checked"] > 20
+
+
+def test_biot_update_without_coupling_terms_on_the_handle_rediscretizes_fully(lib):
+    """An update_discretization call when the handle only holds an MPSA discretization (empty
+    scalar_vector_mappings came first): every row must come back as the full discretization's, none as zero."""
+    from tests._golden import BiotCase
+
+    c = BiotCase("biot_tri2d_3x3_mixed")
+    g = pa.grid_from_raw(c.grid)
+
+    def make(alphas):
+        bc = pa.BoundaryConditionVectorial(g)
+        bc.is_dir, bc.is_neu, bc.is_rob = c.bc["is_dir"].copy(), c.bc["is_neu"].copy(), c.bc["is_rob"].copy()
+        bc.robin_weight = c.bc["robin_weight"]
+        C = type("C", (), {"values": c.stiffness})()
+        maps = {k: type("A", (), {"values": v})() for k, v in alphas.items()}
+        return pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "scalar_vector_mappings": maps})
+
+    d = pa.Biot("mechanics", library=lib)
+    data = make({})
+    d.discretize(g, data)  # MPSA only: no coupling terms on the handle
+    data[pa.PARAMETERS]["mechanics"]["scalar_vector_mappings"] = make(c.alphas)[pa.PARAMETERS]["mechanics"]["scalar_vector_mappings"]
+    data["update_discretization"] = {"modified_cells": np.array([1])}
+    d.update_discretization(g, data)
+    full = make(c.alphas)
+    pa.Biot("mechanics", library=lib).discretize(g, full)
+    md, mf = data[pa.DISCRETIZATION_MATRICES]["mechanics"], full[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    for k in ("stress", "bound_stress"):
+        assert P.rel_max_err(md[k], mf[k]) < 1e-12
+    for k in ("scalar_gradient", "displacement_divergence", "mpsa_consistency"):
+        for key in c.alphas:
+            assert P.rel_max_err(md[k][key], mf[k][key]) < 1e-12, (k, key)
