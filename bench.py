@@ -486,12 +486,14 @@ def main():
     its = int(info["iterations"]) if isinstance(info, dict) and "iterations" in info else 0
     triad_ms = ctx.time_kernel(4, reps=10)
     triad_gbs = 3.0 * 8.0 * (1 << 27) / (triad_ms * 1e-3) / 1e9  # a = b + s c on 3 x 2^27 doubles
+    read_gbs = 8.0 * (1 << 28) / (ctx.time_kernel(5, reps=10) * 1e-3) / 1e9  # read-only stream over 2^28 doubles
     pmc = load_pmc(args.n_side, world)
 
     def hbm_entry(name, kernel, bytes_per_launch, ms, launches_per_step, note, pmc_key=None, extra=None):
         ach = bytes_per_launch / (ms * 1e-3) / 1e9
         e = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": ach / HBM_PEAK_GBS, "frac_of_measured_triad": ach / triad_gbs,
+             "frac_of_measured_read_stream": ach / read_gbs,
              "traffic": (pmc.get(pmc_key, {}) or {}).get("traffic_bytes_per_launch") if pmc_key else None,
              "bytes_per_launch": bytes_per_launch, "ms_per_launch": ms, "launches_per_step": launches_per_step,
              "ms_per_step": ms * launches_per_step, "note": note, "name": name}
@@ -648,7 +650,7 @@ def main():
                        f"{world} z-slab subdomains (1 lattice layer of halo cells recomputed per cut), assembly "
                        "without collectives, BiCGStab with RCCL point-to-point halo exchange + fused all-reduces"},
             "roofline": roofline, "roofline_kernels": kernels[1:], "kernel_ms_per_step": per_step_ms,
-            "hbm_triad_measured_GBs": triad_gbs,
+            "hbm_triad_measured_GBs": triad_gbs, "hbm_read_stream_measured_GBs": read_gbs,
             "assembly": assembly, "operator_api": opapi, "cpu_baseline": cpu, "config_c2": c2, "config_c4": c4,
         }
         if args.phases:

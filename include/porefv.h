@@ -408,8 +408,10 @@ pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out);
  * 3 = AMG smoothing product, 4 = stream triad (no discretization needed). */
 enum { PFV_KERNEL_SPMV_A = 0, PFV_KERNEL_NODE = 1, PFV_KERNEL_FACE = 2,
        PFV_KERNEL_AMG_SMOOTH = 3, /* finest-level smoothing product of the AMG cycle (needs a built hierarchy) */
-       PFV_KERNEL_TRIAD = 4       /* a = b + s c on 3 x 2^27 doubles (3.2 GB moved per launch): the measured
-                                     device bandwidth next to the data-sheet 8 TB/s (SURVEY 8(d) "Metric") */ };
+       PFV_KERNEL_TRIAD = 4,      /* a = b + s c on 3 x 2^27 doubles (3.2 GB moved per launch): the measured
+                                     device bandwidth next to the data-sheet 8 TB/s (SURVEY 8(d) "Metric") */
+       PFV_KERNEL_READ = 5        /* read-only stream over 2^28 doubles (2.1 GB): the ceiling of the read-dominated
+                                     SpMV kernels */ };
 pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms);
 
 /* Test hook: copy the leading `count` entries of an internal FP64 device array to the host (0 = the

@@ -16,6 +16,51 @@
 #include "ad_flux.inc"
 
 namespace pfv {
+#ifndef PFV_EMULATE
+// stream triad a = b + s c (PFV_KERNEL_TRIAD): the measured device bandwidth next to the data-sheet figure
+__global__ void __launch_bounds__(256) k_triad(int64_t n2, D2* __restrict__ a, const D2* __restrict__ b,
+                                               const D2* __restrict__ c) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n2; i += 4 * stride) {
+    D2 x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = b[i + u * stride];
+      y[u] = c[i + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      D2 r;
+      r.x = x[u].x + 0.5 * y[u].x;
+      r.y = x[u].y + 0.5 * y[u].y;
+      a[i + u * stride] = r;
+    }
+  }
+  for (; i < n2; i += stride) {
+    D2 r;
+    r.x = b[i].x + 0.5 * c[i].x;
+    r.y = b[i].y + 0.5 * c[i].y;
+    a[i] = r;
+  }
+}
+// read-only stream (PFV_KERNEL_READ): sum of 2^28 doubles, 16 bytes per lane, four loads in flight; the sums go
+// to a small array so that nothing is optimised away
+__global__ void __launch_bounds__(256) k_read_stream(int64_t n2, const D2* __restrict__ b, double* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double acc = 0.0;
+  for (; i + 3 * stride < n2; i += 4 * stride) {
+    D2 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = b[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += x[u].x + x[u].y;
+  }
+  for (; i < n2; i += stride) acc += b[i].x + b[i].y;
+  if (acc == 1.2345e300) out[0] = acc;  // (never true for the zero-filled buffer: keeps the loads alive)
+}
+#endif
 pfv_ctx_impl::pfv_ctx_impl() = default;
 pfv_ctx_impl::~pfv_ctx_impl() = default;
 }  // namespace pfv
@@ -1438,19 +1483,39 @@ pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms) {
       pfv::D2* a2 = reinterpret_cast<pfv::D2*>(a);
       const pfv::D2* b2 = reinterpret_cast<const pfv::D2*>(b);
       const pfv::D2* c2 = reinterpret_cast<const pfv::D2*>(cc);
-      auto triad = [&] {  // 16 bytes per lane and stream
-        pfv::parallel_for(s, (int64_t)(n / 2), PFV_LAMBDA(int64_t i) {
-          const pfv::D2 x = b2[i], y = c2[i];
-          pfv::D2 r;
-          r.x = x.x + 0.5 * y.x;
-          r.y = x.y + 0.5 * y.y;
-          a2[i] = r;
-        });
+      auto triad = [&] {  // 16 bytes per lane and stream, four independent loads per stream in flight
+#ifdef PFV_EMULATE
+        for (size_t i = 0; i < n / 2; ++i) {
+          a2[i].x = b2[i].x + 0.5 * c2[i].x;
+          a2[i].y = b2[i].y + 0.5 * c2[i].y;
+        }
+#else
+        hipLaunchKernelGGL(pfv::k_triad, dim3(256 * 16), dim3(256), 0, s, (int64_t)(n / 2), a2, b2, c2);
+        PFV_HIP_CHECK(hipGetLastError());
+#endif
       };
       triad();
       tm.start(s);
       for (int i = 0; i < reps; ++i) triad();
       *avg_ms = tm.stop(s) / reps;
+    } else if (kernel == PFV_KERNEL_READ) {
+#ifdef PFV_EMULATE
+      *avg_ms = 0.0;
+#else
+      const size_t n = size_t(1) << 28;
+      pfv::Buf<double> buf;
+      double* a = buf.ensure(n + 8);
+      pfv::be_memset(a, 0, (n + 8) * sizeof(double), s);
+      auto rd = [&] {
+        hipLaunchKernelGGL(pfv::k_read_stream, dim3(256 * 16), dim3(256), 0, s, (int64_t)(n / 2),
+                           reinterpret_cast<const pfv::D2*>(a), a + n);
+        PFV_HIP_CHECK(hipGetLastError());
+      };
+      rd();
+      tm.start(s);
+      for (int i = 0; i < reps; ++i) rd();
+      *avg_ms = tm.stop(s) / reps;
+#endif
     } else if (kernel == PFV_KERNEL_NODE) {
       require(h->have_numeric, "discretize first");
       tm.start(s);
