@@ -1319,3 +1319,61 @@ def amg_robustness_sweep(lib, scale: float = 1.0):
     x, info = ctx.solve("bicgstab", rtol=1e-10, maxit=2000, precond="amg", raise_on_fail=False)
     out["csr_7point_laplacian"] = (A.shape[0], info["iterations"], float(np.linalg.norm(b - A @ x) / np.linalg.norm(b)))
     return out
+
+
+def mpsa_patch_parity_all_matrices(lib, n_side: int = 44, n_random: int = 4):
+    """BASELINE configs[3] (MPSA elasticity, rollers + top traction, perturbed tetrahedra) at full size: all FOUR
+    device matrices (stress, bound_stress, bound_displacement_cell, bound_displacement_face) and the system matrix
+    on patches (8 box corners -- where roller, traction and free faces meet --, 6 side centres, random cells) against
+    the MPSA oracle, rows fetched with pfv_get_matrix_rows."""
+    n = n_side
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.2 / n)
+    nc, nf, nd = g.num_cells, g.num_faces, 3
+    C = pa.FourthOrderTensor(np.ones(nc), np.ones(nc))
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    fc = g.face_centers
+    for axis in range(3):
+        roll = bf[fc[axis, bf] < 1e-9]
+        bc.is_dir[axis, roll] = True
+        bc.is_neu[axis, roll] = False
+    bv = np.zeros((3, nf))
+    top = bf[fc[2, bf] > 1 - 1e-9]
+    bv[2, top] = -g.face_areas[top]
+    raw = pa.grid_to_raw(g)
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(raw)
+    eta = 1.0 / 3.0
+    ctx.mpsa_set_params(C.values, g.cell_volumes, bc.is_dir, bc.is_neu, eta)
+    ctx.mpsa_discretize()
+    ctx.mpsa_assemble(bv.ravel("F"), None)
+    cutter = PatchCutter(raw)
+    ex = lambda idx: (nd * np.asarray(idx)[:, None] + np.arange(nd)[None, :]).ravel()  # noqa: E731
+    worst, checked = {}, 0
+    targets = patch_targets(raw, n_random, seed=6)
+    for c0 in targets:
+        inner = cutter.cells_around(c0)
+        lraw, n_own, cell_gid, face_gid, art = cutter.cut(inner)
+        ldir = bc.is_dir[:, face_gid].copy()
+        lneu = bc.is_neu[:, face_gid].copy()
+        ldir[:, art] = False
+        lneu[:, art] = True
+        ora = so.discretize(lraw, np.ascontiguousarray(C.values[:, :, cell_gid]), {"is_dir": ldir, "is_neu": lneu}, eta=eta)
+        lfaces = np.unique(lraw["cf_indices"][: lraw["cf_indptr"][n_own]])
+        gfaces = face_gid[lfaces]
+        cmap = np.full(nd * nc, -1)
+        cmap[ex(cell_gid)] = np.arange(nd * cell_gid.size)
+        fmap = np.full(nd * nf, -1)
+        fmap[ex(face_gid)] = np.arange(nd * face_gid.size)
+        for k in MPSA_KEYS:
+            m = cmap if k in ("stress", "bound_displacement_cell") else fmap
+            G = ctx.matrix_rows(MPSA_WHICH[k], ex(gfaces)).tocoo()
+            assert np.all(m[G.col] >= 0), (k, c0)
+            Gl = sps_csr((G.data, (G.row, m[G.col])), shape=(nd * gfaces.size, ora[k].shape[1]))
+            err = rel_max_err(Gl, ora[k][ex(lfaces)])
+            worst[k] = max(worst.get(k, 0.0), err)
+            assert err < TOL, (k, c0, err)
+        checked += lfaces.size
+    return {"patches": len(targets), "rows_checked": checked, "worst_rel_err": worst}

@@ -145,3 +145,9 @@ def test_biot_update_without_coupling_terms_on_the_handle_rediscretizes_fully(li
     for k in ("scalar_gradient", "displacement_divergence", "mpsa_consistency"):
         for key in c.alphas:
             assert P.rel_max_err(md[k][key], mf[k][key]) < 1e-12, (k, key)
+
+
+def test_mpsa_patch_parity_machinery_small(lib):
+    """The all-matrices patch test of the GPU suite on a small grid (host emulation)."""
+    out = P.mpsa_patch_parity_all_matrices(lib, 4, n_random=1)
+    assert out["patches"] == 15 and out["rows_checked"] > 100

@@ -111,3 +111,10 @@ def test_full_size_rows_match_oracle_on_patches(lib):
     """BASELINE configs[3] at full size (511 104 tetrahedra, 1.53 M dofs)."""
     out = P.full_size_patch_parity_mpsa(lib, 44)
     assert out["rows_checked"] > 100
+
+
+def test_config_c3_all_four_matrices_on_patches(lib):
+    """BASELINE configs[3] at full size: stress, bound_stress and both displacement-trace matrices on 18 patches
+    (box corners where roller / traction / free faces meet, side centres, random cells)."""
+    out = P.mpsa_patch_parity_all_matrices(lib, 44)
+    assert out["patches"] >= 18 and out["rows_checked"] > 1000
