@@ -440,10 +440,53 @@ class ShardedMpfa:
             comm = _lib.RcclComm(self.ctx, ids[0], rank, world)
             comm.set_halo_plan({p: v.cpu().numpy() for p, v in self.plan.send.items()},
                                {q: v.cpu().numpy() for q, v in self.plan.recv.items()})
-            self._rccl = comm
+            ok = self._rccl_self_test(comm)
         except _lib.PorefvError:
+            comm, ok = None, False
+        # every rank takes the same decision: the native transport is used only if it passed everywhere
+        if world > 1:
+            flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(int(flag.item()))
+        if ok:
+            self._rccl = comm
+        else:
             self._rccl_failed = True
+            if comm is not None and world == 1:
+                comm.close()
         return self._rccl
+
+    def _rccl_self_test(self, comm) -> bool:
+        """One halo exchange and one all-reduce through the native hooks on a vector whose entries are their
+        own global ids: every halo entry must arrive as the id of the cell it stands for, the reduced sums must
+        be the sums over the ranks."""
+        import ctypes as C
+
+        torch = self.torch
+        hooks = _lib.ShardHooks()
+        if self.ctx.lib.pfv_rccl_hooks(comm._c, C.byref(hooks)) != 0:
+            return False
+        gid = torch.from_numpy(np.repeat(self.lp.cell_gid.astype(np.float64), self.bs) * self.bs +
+                               np.tile(np.arange(self.bs, dtype=np.float64), self.lp.cell_gid.size)).to(self.device)
+        x = gid.clone()
+        x[self.n_own:] = -1.0
+        red = torch.tensor([float(self.n_own), 1.0], dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device)
+        stream.synchronize()
+        sp = C.c_void_p(stream.cuda_stream)
+        if hooks.exchange_halo(hooks.user, C.c_void_p(x.data_ptr()), sp) != 0:
+            return False
+        if hooks.allreduce_sum(hooks.user, C.c_void_p(red.data_ptr()), 2, sp) != 0:
+            return False
+        stream.synchronize()
+        world = self.dist.get_world_size() if self.dist is not None else 1
+        if not bool(torch.equal(x, gid)) or float(red[1].item()) != float(world):
+            return False
+        if self.dist is not None and world > 1:
+            tot = torch.tensor([self.n_own], dtype=torch.int64, device=self.device)
+            self.dist.all_reduce(tot)
+            return float(red[0].item()) == float(tot.item())
+        return True
 
     def _solve_library(self, method, rtol, maxit, precond):
         torch = self.torch
