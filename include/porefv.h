@@ -110,6 +110,8 @@ typedef struct {
                                      + 2 nd nh (3 n_b) (boundary columns) + ~60 nd^2 per sub-cell (nK, D^-1, omega) */
   int64_t node_table_doubles;     /* doubles in the per-node response tables (what the node kernel writes and the
                                      face kernel reads) */
+  int64_t amg_maps_reused;        /* 1: the last AMG setup kept the aggregates of the previous one (same pattern,
+                                     new values: only the Galerkin products were redone), 0: full setup */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);

@@ -227,6 +227,7 @@ struct pfv_ctx_impl {
   int precond = 0;                   // PFV_PRECOND_*
   std::unique_ptr<Amg> amg;          // hierarchy of the active system (rebuilt when the system changes)
   const double* amg_for_val = nullptr;  // the matrix values the hierarchy was built from
+  unsigned long long symbolic_epoch = 0;  // bumped by every symbolic phase: saved AMG aggregates die with it
   std::unique_ptr<Amg> amg_block;    // pfv_amg_setup: hierarchy of the leading block (sharded solves)
   CsrPattern pat_block;
   Buf<double> val_block;

@@ -1254,6 +1254,7 @@ pfv_status pfv_amg_setup(pfv_ctx* h, int64_t n_own) {
     h->stats.amg_operator_complexity = h->amg_block->op_complexity;
     h->stats.amg_levels = (int64_t)h->amg_block->nlev;
     h->stats.amg_coarsest_rows = h->amg_block->lev[h->amg_block->nlev - 1]->n;
+    h->stats.amg_maps_reused = h->amg_block->reused ? 1 : 0;
   });
 }
 
@@ -1344,6 +1345,7 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
         h->stats.amg_operator_complexity = h->amg->op_complexity;
         h->stats.amg_levels = (int64_t)h->amg->nlev;
         h->stats.amg_coarsest_rows = h->amg->lev[h->amg->nlev - 1]->n;
+        h->stats.amg_maps_reused = h->amg->reused ? 1 : 0;
       }
       M.amg = h->amg.get();
       Mp = &M;

@@ -542,6 +542,27 @@ def amg_preconditioner(lib, g, seed=2, hetero_sigma=0.5):
     assert np.array_equal(x2, x3) and info2["iterations"] == info3["iterations"]
     st = d.context(g).stats()
     assert st["amg_levels"] >= 2 and 1.0 < st["amg_operator_complexity"] < 2.0
+    assert st["amg_maps_reused"] == 0  # first hierarchy of this pattern
+    # new parameter values on the same grid: the patterns stay, the hierarchy keeps its aggregates and
+    # redoes the Galerkin products only; the solve is still right and about as fast
+    sc2 = sc * np.exp(0.1 * rng.standard_normal(nc))
+    kw2 = {k: v * sc2 / sc for k, v in kw.items()}
+    data[pa.PARAMETERS]["flow"]["second_order_tensor"] = pa.SecondOrderTensor(**kw2)
+    d.discretize(g, data)
+    A2, b2 = d.assemble_matrix_rhs(g, data)
+    xo2 = spla.spsolve(A2.tocsc(), b2 + src)
+    xr, ir = d.solve(g, data, source=src, method="bicgstab", rtol=1e-12, precond="amg")
+    st2 = d.context(g).stats()
+    assert st2["amg_maps_reused"] == 1
+    assert ir["converged"] and np.linalg.norm(xr - xo2) <= TOL * np.linalg.norm(xo2)
+    assert ir["iterations"] <= out["bicgstab"] + 4, (ir["iterations"], out)
+    # a rebuilt discretization (new symbolic phase) never reuses
+    data[pa.PARAMETERS]["flow"]["hip_rebuild_topology"] = True
+    d.discretize(g, data)
+    d.assemble_matrix_rhs(g, data)
+    xf, i_f = d.solve(g, data, source=src, method="bicgstab", rtol=1e-12, precond="amg")
+    assert d.context(g).stats()["amg_maps_reused"] == 0
+    assert np.linalg.norm(xf - xo2) <= TOL * np.linalg.norm(xo2)
     return out, ij["iterations"], st
 
 
