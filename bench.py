@@ -138,8 +138,8 @@ def bench_config_c4(pa, device_index: int, rtol: float, precond: str, steps: int
     # executed flops, 2 n^3 for the Gauss-Jordan inverse + ~40 % for the products that follow it
     n_int = (n - 1) ** 3
     mpsa_flops = n_int * 2.0 * 108 ** 3 * 1.4
-    node_roofline = {"bound": "fp64", "kernel": "mpsa node kernel (256 threads per interaction region, column-split register "
-                     "Gauss-Jordan, n = 108)", "ms_per_launch": st["node_ms"], "flops_per_launch_estimate": mpsa_flops,
+    node_roofline = {"bound": "fp64", "kernel": "mpsa node kernel (512 threads per interaction region; block-cyclic register "
+                     "Gauss-Jordan on 256 of them, 8x8 entries per thread, n = 108)", "ms_per_launch": st["node_ms"], "flops_per_launch_estimate": mpsa_flops,
                      "achieved": mpsa_flops / (st["node_ms"] * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                      "frac": mpsa_flops / (st["node_ms"] * 1e-3) / 78.6e12}
     return {"workload": "BASELINE configs[3] on 1 GPU: MPSA elasticity, 511104 tetrahedra, 3 dof/cell, rollers + top traction",
