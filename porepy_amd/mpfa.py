@@ -154,27 +154,43 @@ def estimate_device_bytes(sd) -> int:
     return int(1.15 * (tables + patterns + values + topo + grid + staging + solver))
 
 
-def check_device_memory(ctx, sd, partition_arguments=None) -> None:
-    """`partition_arguments` (mpfa.py:160-161, 246-372) bounds the reference's peak host memory by
-    discretizing overlapping sub-grids one after another.  On the device the footprint is known before
-    anything is allocated; the discretization is done in one piece if it fits the free HBM and refused with
-    the numbers otherwise -- a multi-GPU node shards it (distributed.ShardedMpfa), and rows can be pulled
-    patch by patch (`Context.matrix_rows`, `LazyCsr`) instead of as whole matrices."""
+def plan_subproblems(sd, partition_arguments, free_bytes) -> int:
+    """Number of overlapping sub-grids the discretization is done in (reference: mpfa.py:157-161 with
+    _fvutils.parse_partition_arguments, the peak-memory estimate of mpfa.py:1315-1355 and
+    _fvutils.subproblems, _fvutils.py:414-539).  ``num_subproblems`` is taken as given; ``max_memory`` (bytes)
+    bounds the estimated device footprint of one piece; without either the grid is split only when it does
+    not fit the free HBM of the device."""
     import logging
+    import math
 
+    pa = dict(partition_arguments or {})
     need = estimate_device_bytes(sd)
-    free = ctx.free_device_bytes()
-    if partition_arguments:
+    if "num_subproblems" in pa:
+        n = max(1, int(pa["num_subproblems"]))
+    elif "max_memory" in pa:
+        n = max(1, math.ceil(need / float(pa["max_memory"])))
+    elif free_bytes is not None and need > 0.9 * free_bytes:
+        n = math.ceil(need / (0.6 * free_bytes))  # pieces carry their overlap and the merge buffers
+    else:
+        n = 1
+    n = min(n, max(1, sd.num_cells))
+    if n > 1:
         logging.getLogger("porepy_amd").info(
-            "partition_arguments=%r: the grid is discretized in one piece on the device (estimated %.1f GB of "
-            "%.1f GB free); the key only bounds host memory in the reference", partition_arguments,
-            need / 1e9, (free or 0) / 1e9)
-    if free is not None and need > free:
-        raise MemoryError(
-            f"MPFA on this grid needs about {need / 1e9:.1f} GB of device memory, {free / 1e9:.1f} GB are free "
-            f"({sd.num_cells} cells; a 288 GB MI355X holds about 14 M tetrahedra per handle). Shard the grid over "
-            "several GPUs (porepy_amd.distributed.ShardedMpfa) or discretize it in pieces with "
-            "specified_cells / specified_faces.")
+            "MPFA on %d cells in %d overlapping pieces (estimated %.1f GB in one piece, %s GB free)", sd.num_cells, n,
+            need / 1e9, "?" if free_bytes is None else f"{free_bytes / 1e9:.1f}")
+    return n
+
+
+def partition_cells(sd, nparts: int) -> np.ndarray:
+    """Owner piece of every cell: equal chunks of the cells along a Morton curve of their centres (compact
+    pieces, small overlaps; the reference partitions with metis / structured blocks / coordinates,
+    grids/partition.py:269-297 -- any partition yields the same matrices)."""
+    from .distributed import morton_order
+
+    order = morton_order(np.asarray(sd.cell_centers), sd.dim)
+    owner = np.empty(sd.num_cells, dtype=np.int32)
+    owner[order] = (np.arange(sd.num_cells, dtype=np.int64) * nparts) // max(sd.num_cells, 1)
+    return owner
 
 
 class Mpfa:
@@ -197,6 +213,8 @@ class Mpfa:
         self._tpfa_discr = None  # grids of dimension < 2
         self._plane: dict = {}  # id(sd) -> (2, 3) in-plane basis of a tilted 2-D grid, or None
         self._periodic: dict = {}  # id(sd) -> PeriodicMerge of a grid with periodic faces, or None
+        self._split: dict = {}  # id(sd) -> (sd, A) of a grid discretized in pieces (no whole-grid handle exists)
+        self._probe = None  # handle without a grid, for memory queries
 
     # ---- Discretization API ---------------------------------------------------------
     def ndof(self, sd) -> int:
@@ -252,6 +270,104 @@ class Mpfa:
         if merge is not None:
             ctx.set_periodic(merge.native, merge.shift)
 
+    def _free_device_bytes(self):
+        if self._probe is None:
+            self._probe = _lib.Context(self.device, self._library)
+        return self._probe.free_device_bytes()
+
+    def _discretize_in_pieces(self, sd, data: dict, nparts: int, eta: float) -> None:
+        """Memory-bounded discretization (mpfa.py:246-372, _fvutils.py:414-539): the cells are partitioned, every
+        piece is extended by one node-ring of cells (all interaction regions of its own cells' faces are then
+        complete), discretized on the device on its own, and the rows of the faces of its own cells are merged
+        into the global matrices on the host; a face between two pieces is computed by both and averaged, as
+        the reference does.  One piece is resident in HBM at a time.  The system matrix div @ flux is taken
+        from the pieces too (rows of a piece's own cells are complete there)."""
+        import scipy.sparse as sps
+
+        from .distributed import extract_subdomain
+
+        pd = data[PARAMETERS][self.keyword]
+        md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
+        raw = grid_to_raw(sd)
+        nd, nc, nf = sd.dim, sd.num_cells, sd.num_faces
+        kval = np.asarray(pd["second_order_tensor"].values, dtype=float)
+        bnd = pd["bc"]
+        flags = bc_flags(bnd)
+        robin = np.asarray(bnd.robin_weight, dtype=float)
+        owner = partition_cells(sd, nparts)
+        ncols = {"flux": nc, "bound_flux": nf, "bound_pressure_cell": nc, "bound_pressure_face": nf,
+                 "vector_source": nd * nc, "bound_pressure_vector_source": nd * nc}
+        acc = {name: ([], [], []) for name, _ in _KEYS}
+        sysacc = ([], [], [])
+        count = np.zeros(nf, dtype=np.int64)
+        for r in range(nparts):
+            if not np.any(owner == r):
+                continue
+            lp = extract_subdomain(raw, owner, r)
+            ctx = _lib.Context(self.device, self._library)
+            try:
+                ctx.set_grid(lp.raw)
+                lfl = flags[lp.face_gid].copy()
+                lfl[lp.artificial_boundary] = _lib.BC_NEU  # never touches a node of an own cell
+                ctx.set_params(np.ascontiguousarray(kval[:, :, lp.cell_gid]), lfl,
+                               np.ascontiguousarray(robin[lp.face_gid]), eta, None)
+                try:
+                    ctx.discretize(rebuild_topology=True)
+                except _lib.PorefvError as e:
+                    if e.status == 1:
+                        raise ValueError("Error in inversion of local linear systems") from e
+                    if e.status == 2:
+                        raise AssertionError(e.message) from e
+                    raise
+                cfp = lp.raw["cf_indptr"]
+                own_faces = np.unique(lp.raw["cf_indices"][: cfp[lp.n_own]])  # faces of the piece's own cells
+                count[lp.face_gid[own_faces]] += 1
+                vcol = (nd * lp.cell_gid[:, None] + np.arange(nd)[None, :]).ravel()
+                for name, which in _KEYS:
+                    M = ctx.matrix_rows(which, own_faces).tocoo()
+                    cmap = lp.face_gid if ncols[name] == nf else (vcol if "vector_source" in name else lp.cell_gid)
+                    rr, cc, vv = acc[name]
+                    rr.append(lp.face_gid[own_faces][M.row])
+                    cc.append(cmap[M.col])
+                    vv.append(M.data)
+                ctx.assemble(np.zeros(lp.face_gid.size), None, None)
+                S = ctx.matrix_rows(_lib.MAT_SYSTEM, np.arange(lp.n_own)).tocoo()
+                sysacc[0].append(lp.cell_gid[S.row])
+                sysacc[1].append(lp.cell_gid[S.col])
+                sysacc[2].append(S.data)
+            finally:
+                ctx.close()
+        scale = 1.0 / np.maximum(count, 1)
+        for name, _ in _KEYS:
+            rr, cc, vv = (np.concatenate(x) if x else np.zeros(0) for x in acc[name])
+            M = sps.coo_matrix((vv * scale[rr.astype(np.int64)], (rr, cc)), shape=(nf, ncols[name])).tocsr()
+            M.sum_duplicates()
+            M.sort_indices()
+            md[name] = M
+        A = sps.coo_matrix((np.concatenate(sysacc[2]), (np.concatenate(sysacc[0]), np.concatenate(sysacc[1]))),
+                           shape=(nc, nc)).tocsr()
+        A.sum_duplicates()
+        A.sort_indices()
+        self._split[id(sd)] = (sd, A)
+        self._contexts.pop(id(sd), None)
+        pd["active_cells"] = np.arange(nc)
+        pd["active_faces"] = np.arange(nf)
+
+    def _split_system(self, sd, data: dict, source=None):
+        """(A, b) of a grid discretized in pieces: A from the pieces' device-side div @ flux, b from the merged
+        boundary / vector-source matrices (two host SpMVs, fv_elliptic.py:98-112)."""
+        pd = data[PARAMETERS][self.keyword]
+        md = data[DISCRETIZATION_MATRICES][self.keyword]
+        div = sd.cell_faces.T.tocsr()
+        q = md["bound_flux"] @ np.asarray(pd["bc_values"], dtype=float)
+        vs = self._vector_source(sd, pd)
+        if vs is not None:
+            q = q + md["vector_source"] @ vs
+        b = -(div @ q)
+        if source is not None:
+            b = b + np.asarray(source, dtype=float)
+        return self._split[id(sd)][1], b
+
     def _tpfa(self):
         if self._tpfa_discr is None:
             from .tpfa import Tpfa
@@ -292,9 +408,22 @@ class Mpfa:
             eta_sub = np.asarray(eta, dtype=float)
             eta = 0.0
         note_ignored_parameters(pd, self.keyword)
+        self._split.pop(id(sd), None)
+        ent = self._contexts.get(id(sd))
+        if not (ent is not None and ent[0] is sd and ent[1].has_discretization):
+            # (a handle that already holds this grid's discretization reuses its buffers: it fits)
+            nparts = plan_subproblems(sd, pd.get("partition_arguments"), self._free_device_bytes())
+            if nparts > 1:
+                plain = not (partial or update or subface or eta_sub is not None or hasattr(sd, "periodic_face_map")
+                             or vdim != sd.dim or (sd.dim == 2 and plane_basis(grid_to_raw(sd)["nodes"]) is not None))
+                if plain:
+                    return self._discretize_in_pieces(sd, data, nparts, float(eta))
+                import logging
+
+                logging.getLogger("porepy_amd").warning(
+                    "partition_arguments: partial updates, conditions per sub-face, per-sub-face eta, periodic or "
+                    "tilted 2-D grids are discretized in one piece")
         ctx = self.context(sd)
-        if not ctx.has_discretization:  # (a handle that already holds this grid's discretization reuses its buffers)
-            check_device_memory(ctx, sd, pd.get("partition_arguments"))
         T = self._plane.get(id(sd))
         merge = self._periodic.get(id(sd))
         if merge is not None and (partial or update or subface):
@@ -419,6 +548,9 @@ class Mpfa:
         if sd.dim < 2:
             return self._tpfa().assemble_matrix_rhs(sd, data)
         pd = data[PARAMETERS][self.keyword]
+        sp = self._split.get(id(sd))
+        if sp is not None and sp[0] is sd:
+            return self._split_system(sd, data)
         ent = self._contexts.get(id(sd))
         if ent is None or ent[0] is not sd:
             raise RuntimeError("discretize(sd, data) must run on this object before assemble_matrix_rhs")
@@ -477,6 +609,13 @@ class Mpfa:
             return self._tpfa().solve(sd, data, source=source, method=method, rtol=rtol, maxit=maxit, x0=x0,
                                       restart=restart, precond=precond)
         pd = data[PARAMETERS][self.keyword]
+        sp = self._split.get(id(sd))
+        if sp is not None and sp[0] is sd:
+            from .solvers import solve_csr
+
+            A, b = self._split_system(sd, data, source)
+            return solve_csr(A, b, method=method, rtol=rtol, maxit=maxit, restart=restart, device=self.device,
+                             library=self._library, precond=precond)
         ent = self._contexts.get(id(sd))
         if ent is None or ent[0] is not sd:
             raise RuntimeError("discretize(sd, data) must run on this object before solve")

@@ -1398,3 +1398,31 @@ def mpsa_patch_parity_all_matrices(lib, n_side: int = 44, n_random: int = 4):
             assert err < TOL, (k, c0, err)
         checked += lfaces.size
     return {"patches": len(targets), "rows_checked": checked, "worst_rel_err": worst}
+
+
+def split_matches_one_piece(lib, g, K, bc, bv, split_kwargs, monkeypatch=None, free=None):
+    import scipy.sparse.linalg as spla
+
+    one = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": bv})
+    d1 = pa.Mpfa("flow", library=lib)
+    d1.discretize(g, one)
+    A1, b1 = d1.assemble_matrix_rhs(g, one)
+    if monkeypatch is not None:
+        monkeypatch.setattr(pa._lib.Context, "free_device_bytes", lambda self: free)
+    many = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": bv, **split_kwargs})
+    d2 = pa.Mpfa("flow", library=lib)
+    d2.discretize(g, many)
+    assert id(g) in d2._split and id(g) not in d2._contexts  # no whole-grid handle was created
+    m1, m2 = one[pa.DISCRETIZATION_MATRICES]["flow"], many[pa.DISCRETIZATION_MATRICES]["flow"]
+    for name in ("flux", "bound_flux", "bound_pressure_cell", "bound_pressure_face", "vector_source",
+                 "bound_pressure_vector_source"):
+        ref = m1[name]
+        assert m2[name].shape == ref.shape
+        assert abs(m2[name] - ref).max() <= 1e-12 * max(abs(ref).max(), 1e-300), name
+    A2, b2 = d2.assemble_matrix_rhs(g, many)
+    assert abs(A2 - A1).max() <= 1e-12 * abs(A1).max()
+    assert np.linalg.norm(b2 - b1) <= 1e-12 * np.linalg.norm(b1)
+    x, info = d2.solve(g, many, rtol=1e-12)
+    xo = spla.spsolve(A1.tocsc(), b1)
+    assert info["converged"] and np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+    assert np.array_equal(many[pa.PARAMETERS]["flow"]["active_faces"], np.arange(g.num_faces))

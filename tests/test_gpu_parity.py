@@ -338,3 +338,24 @@ def test_amg_on_systems_other_than_the_benchmark(lib):
               "quad2d_channels_1e4": 64, "csr_7point_laplacian": 44}
     for k, (n, its, res) in out.items():
         assert res < 1.05e-10 and its <= bounds[k], (k, n, its, res)
+
+
+def test_partition_arguments_discretize_in_pieces(lib):
+    """partition_arguments (mpfa.py:157-161, 246-372) on the product library: overlapping pieces, one resident
+    in HBM at a time, the merged matrices, the system and its solution equal the one-piece ones."""
+    g = pa.StructuredTetrahedralGrid([6, 6, 6], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.02, seed=3)
+    rng = np.random.default_rng(3)
+    nc = g.num_cells
+    K = pa.SecondOrderTensor(kxx=1 + rng.random(nc), kyy=2 + rng.random(nc), kzz=0.5 + rng.random(nc),
+                             kxy=0.2 * rng.random(nc))
+    bf = g.get_all_boundary_faces()
+    xf = g.face_centers[0, bf]
+    dirf = bf[(xf < 1e-9) | (xf > 1 - 1e-9)]
+    bc = pa.BoundaryCondition(g, dirf, ["dir"] * dirf.size)
+    bv = np.zeros(g.num_faces)
+    bv[dirf] = g.face_centers[0, dirf]
+    neu = np.setdiff1d(bf, dirf)
+    bv[neu[::7]] = 0.01
+    P.split_matches_one_piece(lib, g, K, bc, bv, dict(partition_arguments={"num_subproblems": 5}))

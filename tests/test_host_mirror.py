@@ -96,15 +96,40 @@ def test_grid_changes_after_the_first_call_are_seen(lib):
     assert abs(f1 - f0).max() > 1e-6
 
 
-def test_memory_guard_refuses_before_allocating(lib, monkeypatch):
+def test_partition_arguments_discretize_in_pieces(lib):
+    """partition_arguments (mpfa.py:157-161, 246-372): overlapping pieces, one resident at a time, same matrices."""
+    g, K, bc, bv = _problem()
+    P.split_matches_one_piece(lib, g, K, bc, bv, dict(partition_arguments={"num_subproblems": 4}))
+    need = pa.mpfa.estimate_device_bytes(g)
+    P.split_matches_one_piece(lib, g, K, bc, bv, dict(partition_arguments={"max_memory": need / 2.5}))
+
+
+def test_pieces_on_a_2d_grid_with_mixed_conditions(lib):
+    g = pa.CartGrid([9, 7], [1.0, 1.0])
+    g.compute_geometry()
+    rng = np.random.default_rng(5)
+    nc = g.num_cells
+    K = pa.SecondOrderTensor(kxx=1 + rng.random(nc), kyy=2 + rng.random(nc), kxy=0.3 * rng.random(nc))
+    bf = g.get_all_boundary_faces()
+    left = bf[g.face_centers[0, bf] < 1e-9]
+    right = bf[g.face_centers[0, bf] > 1 - 1e-9]
+    bc = pa.BoundaryCondition(g, np.concatenate([left, right]), ["dir"] * left.size + ["rob"] * right.size)
+    bc.robin_weight[right] = 2.0
+    bv = np.zeros(g.num_faces)
+    bv[left] = 1.0
+    bv[right] = 0.3
+    bv[np.setdiff1d(bf, np.concatenate([left, right]))[::3]] = -0.05
+    P.split_matches_one_piece(lib, g, K, bc, bv, dict(partition_arguments={"num_subproblems": 3}))
+
+
+def test_grid_larger_than_free_memory_is_split(lib, monkeypatch):
     g, K, bc, bv = _problem()
     need = pa.mpfa.estimate_device_bytes(g)
     assert 1e5 < need < 1e9
-    monkeypatch.setattr(pa._lib.Context, "free_device_bytes", lambda self: need // 2)
-    with pytest.raises(MemoryError, match="Shard the grid"):
-        pa.Mpfa("flow", library=lib).discretize(g, _data(K, bc, bv))
-    monkeypatch.setattr(pa._lib.Context, "free_device_bytes", lambda self: 10 * need)
-    pa.Mpfa("flow", library=lib).discretize(g, _data(K, bc, bv, partition_arguments={"num_subproblems": 4}))
+    assert pa.mpfa.plan_subproblems(g, None, 10 * need) == 1
+    assert pa.mpfa.plan_subproblems(g, None, need // 2) == 4
+    assert pa.mpfa.plan_subproblems(g, {"num_subproblems": 3}, 10 * need) == 3
+    P.split_matches_one_piece(lib, g, K, bc, bv, {}, monkeypatch, need // 2)
 
 
 def test_memory_estimate_covers_the_benchmark_grid():
