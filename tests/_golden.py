@@ -20,7 +20,7 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "partial_", "tilted_", "tpfa_", "tpfaad_", "biot_", "subface_", "periodic_", "adflux_", "md_"))]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "mpsasub_", "partial_", "tilted_", "tpfa_", "tpfaad_", "biot_", "subface_", "periodic_", "adflux_", "md_"))]
 
 
 def mpsa_case_names():
@@ -29,6 +29,28 @@ def mpsa_case_names():
 
 
 MPSA_KEYS = ("stress", "bound_stress", "bound_displacement_cell", "bound_displacement_face")
+
+
+def mpsa_subface_case_names():
+    return [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "mpsasub_*.npz")))]
+
+
+class MpsaSubfaceCase:
+    """MPSA fixture with conditions per sub-face (oracle/gen_golden_mpsa_subface.py, from the reference)."""
+
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.grid["name"] = str(self.grid["name"])
+        self.bc = {"is_dir": z["bc_is_dir"], "is_neu": z["bc_is_neu"], "is_rob": z["bc_is_rob"],
+                   "robin_weight": z["bc_robin_weight"]}
+        self.stiffness = z["stiffness"]
+        self.ref = {}
+        for k in MPSA_KEYS:
+            shape = tuple(int(v) for v in z[f"ref_{k}_shape"])
+            self.ref[k] = sps.csr_matrix((z[f"ref_{k}_data"], z[f"ref_{k}_indices"], z[f"ref_{k}_indptr"]), shape=shape)
 
 
 class MpsaCase:

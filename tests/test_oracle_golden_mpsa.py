@@ -4,7 +4,8 @@ import pytest
 import scipy.sparse.linalg as spla
 
 from oracle import mpsa_oracle as so
-from tests._golden import MPSA_KEYS, MpsaCase, check_pattern, mpsa_case_names, rel_max_err
+from tests._golden import (MPSA_KEYS, MpsaCase, MpsaSubfaceCase, check_pattern, mpsa_case_names,
+                           mpsa_subface_case_names, rel_max_err)
 
 TOL = 1e-10
 
@@ -26,6 +27,19 @@ def test_mpsa_oracle_matches_reference(name):
     if "hetero" not in name:
         x = spla.spsolve(A.tocsc(), b)
         assert np.linalg.norm(x - c.ref_x) <= 1e-9 * np.linalg.norm(c.ref_x)
+
+
+@pytest.mark.parametrize("name", mpsa_subface_case_names())
+def test_mpsa_oracle_with_conditions_per_subface(name):
+    """mpsa.py:712-720, 752-754, 780-781, 1127-1138: sub-face rows of stress / bound_stress, sub-face columns of
+    the boundary matrices, Neumann data integrated over the sub-face."""
+    c = MpsaSubfaceCase(name)
+    out = so.discretize(c.grid, c.stiffness, c.bc)
+    for k in MPSA_KEYS:
+        assert out[k].shape == c.ref[k].shape, (name, k)
+        assert rel_max_err(out[k], c.ref[k]) < TOL, (name, k)
+        subset, outside, _ = check_pattern(out[k], c.ref[k])
+        assert subset and outside < 1e-12, (name, k, outside)
 
 
 @pytest.mark.parametrize("key", ["cart_homogeneous", "cart_heterogeneous",
