@@ -316,6 +316,21 @@ pfv_status pfv_mpsa_set_robin(pfv_ctx* h, const uint8_t* bc_rob_bits, const doub
  * pfv_mpsa_set_params (which resets it). */
 pfv_status pfv_mpsa_set_basis(pfv_ctx* h, const double* basis_ddn);
 
+/* Conditions per SUB-FACE (numerics/fv/mpsa.py:712-720: a BoundaryConditionVectorial with one entry per sub-face;
+ * :752-754, 780-781 the outputs; :1127-1138 Neumann / Robin data integrated over the sub-face, not divided by
+ * #nodes).  Arrays with one entry per sub-face in the order of the SORTED face_nodes CSC arrays: component bit
+ * masks as in pfv_mpsa_set_params, optional Robin flags and weights (nd, nd, Nsf) C-order (NULL = identity).
+ * After this call pfv_mpsa_discretize fills
+ *   PFV_MAT_STRESS                   (nd Nsf x nd Nc)    one row block per sub-face
+ *   PFV_MAT_BOUND_STRESS             (nd Nsf x nd Nsf)
+ *   PFV_MAT_BOUND_DISPLACEMENT_CELL  (nd Nf  x nd Nc)    as with conditions per face
+ *   PFV_MAT_BOUND_DISPLACEMENT_FACE  (nd Nf  x nd Nsf)
+ * and pfv_mpsa_assemble refuses (the caller collapses the sub-face rows first, as with the reference).
+ * bc_dir_bits_sub = NULL returns to conditions per face; pfv_mpsa_set_params resets it.  Not combined with a
+ * face-wise basis, Biot coupling terms or partial updates. */
+pfv_status pfv_mpsa_set_subface_bc(pfv_ctx* h, const uint8_t* bc_dir_bits_sub, const uint8_t* bc_neu_bits_sub,
+                                   const uint8_t* bc_rob_bits_sub, const double* robin_weight_dds);
+
 /* Mpsa._stress_discretization (numerics/fv/mpsa.py:531-782) on the device; fills matrices 7-10 */
 pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags);
 

@@ -36,7 +36,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc", "pfv_mpsa_set_subface_bc",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
     "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces", "pfv_solve_sharded", "pfv_tpfa_transmissibility_ad",
     "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
@@ -121,6 +121,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpfa_set_subface_bc.restype = C.c_int
     lib.pfv_mpsa_set_basis.argtypes = [_h, _dp]
     lib.pfv_mpsa_set_basis.restype = C.c_int
+    lib.pfv_mpsa_set_subface_bc.argtypes = [_h, _up, _up, _up, _dp]
+    lib.pfv_mpsa_set_subface_bc.restype = C.c_int
     lib.pfv_mpsa_set_robin.argtypes = [_h, _up, _dp]
     lib.pfv_mpsa_set_robin.restype = C.c_int
     lib.pfv_reset_stream.argtypes = [_h]
@@ -432,6 +434,28 @@ class Context:
                 raise ValueError("basis must have shape (nd, nd, Nf)")
             if not np.array_equal(B, np.tile(np.eye(self.nd)[:, :, None], (1, 1, self.nf))):
                 self._check(self.lib.pfv_mpsa_set_basis(self._h, _ptr(B, _dp)))
+
+    def mpsa_set_subface_bc(self, is_dir_sub, is_neu_sub, is_rob_sub=None, robin_weight_sub=None):
+        """Conditions per sub-face (include/porefv.h: pfv_mpsa_set_subface_bc): boolean (nd, Nsf) arrays in the
+        order of the sorted face_nodes CSC arrays, optional Robin weights (nd, nd, Nsf).  After mpsa_set_params."""
+        is_dir, is_neu = np.asarray(is_dir_sub, bool), np.asarray(is_neu_sub, bool)
+        if is_dir.shape != (self.nd, self.nsf) or is_neu.shape != (self.nd, self.nsf):
+            raise ValueError("is_dir / is_neu per sub-face must have shape (nd, Nsf)")
+        wts = (1 << np.arange(self.nd))[:, None]
+        dbits = np.ascontiguousarray((is_dir * wts).sum(axis=0), dtype=np.uint8)
+        nbits = np.ascontiguousarray((is_neu * wts).sum(axis=0), dtype=np.uint8)
+        rbits = W = None
+        if is_rob_sub is not None and np.any(is_rob_sub):
+            is_rob = np.asarray(is_rob_sub, bool)
+            if is_rob.shape != (self.nd, self.nsf):
+                raise ValueError("is_rob per sub-face must have shape (nd, Nsf)")
+            rbits = np.ascontiguousarray((is_rob * wts).sum(axis=0), dtype=np.uint8)
+            if robin_weight_sub is not None:
+                W = _f64(robin_weight_sub)
+                if W.shape != (self.nd, self.nd, self.nsf):
+                    raise ValueError("robin_weight per sub-face must have shape (nd, nd, Nsf)")
+        self._check(self.lib.pfv_mpsa_set_subface_bc(self._h, _ptr(dbits, _up), _ptr(nbits, _up), _ptr(rbits, _up),
+                                                     _ptr(W, _dp)))
 
     # ---- Biot coupling terms ------------------------------------------------------------
     def biot_set_alphas(self, alphas):

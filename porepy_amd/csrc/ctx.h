@@ -178,6 +178,14 @@ struct pfv_ctx_impl {
   bool have_mpsa_robin = false;
   Buf<double> mpsa_basis;            // [nd*nd][Nf] boundary basis (BoundaryConditionVectorial.basis)
   bool have_mpsa_basis = false;
+  // conditions per sub-face (mpsa.py:712-720): flags / weights per sub-face replace the per-face ones, stress and
+  // bound_stress keep sub-face rows, the boundary matrices sub-face columns
+  bool mpsa_subface_bc = false, have_mpsa_sub_symbolic = false;
+  Buf<uint8_t> bc_dirbits_sub, bc_neubits_sub, bc_robbits_sub;
+  Buf<double> mpsa_robw_sub;         // [nd*nd][Nsf]
+  bool have_mpsa_robin_sub = false;
+  CsrPattern pat_sstress, pat_sbstress, pat_bdf_s, pat_sbdface;  // expansions of pat_sflux / pat_sbound; (Nf x Nsf) and its expansion
+  Buf<uint8_t> bdf_src;              // [2 x nnz(pat_bdf_s)] (node position in the face, local boundary sub-face) of every entry
   double mpsa_eta = 0.0;
   Buf<int32_t> cell_nnodes;          // [nc] distinct nodes of a cell (node-volume weights)
   Buf<int64_t> node_eptr, node_ebptr;  // [nn+1] offsets of the per-node expanded rows (cells / boundary faces)
@@ -253,11 +261,13 @@ struct pfv_ctx_impl {
       case PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE:
         return pat_vs;
       case PFV_MAT_STRESS:
+        return mpsa_subface_bc ? pat_sstress : pat_stress;
       case PFV_MAT_BOUND_DISPLACEMENT_CELL:
         return pat_stress;
       case PFV_MAT_BOUND_STRESS:
+        return mpsa_subface_bc ? pat_sbstress : pat_bstress;
       case PFV_MAT_BOUND_DISPLACEMENT_FACE:
-        return pat_bstress;
+        return mpsa_subface_bc ? pat_sbdface : pat_bstress;
       case PFV_MAT_MECH_SYSTEM:
         return pat_Am;
       case PFV_MAT_USER_SYSTEM:

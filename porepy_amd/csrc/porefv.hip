@@ -256,8 +256,8 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     h->biot_rows_complete = false;
     h->rows_complete = false;
     h->rows_complete_m = false;
-    h->have_sub_symbolic = false;
-    h->subface_bc = false;
+    h->have_sub_symbolic = h->have_mpsa_sub_symbolic = false;
+    h->subface_bc = h->mpsa_subface_bc = false;
     h->tpfa_mode = false;
     h->have_mpsa_numeric = h->have_mpsa_symbolic = h->have_mech_system = false;
     h->active.valid = false;
@@ -365,7 +365,7 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
         h->stats.symbolic_ms = tm.stop(s);
       }
       h->tpfa_mode = false;
-      h->have_sub_symbolic = false;
+      h->have_sub_symbolic = h->have_mpsa_sub_symbolic = false;
     }
     if (!node_done) {
       tm.start(s);
@@ -712,6 +712,7 @@ pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const do
     upload(h->bc_neubits, bc_neu_bits, (size_t)h->nf, s);
     h->have_mpsa_robin = false;
     h->have_mpsa_basis = false;
+    h->mpsa_subface_bc = false;
     h->mpsa_eta = eta;
     h->have_mpsa_params = true;
     h->have_mpsa_numeric = h->have_mech_system = false;
@@ -753,6 +754,44 @@ pfv_status pfv_mpsa_set_basis(pfv_ctx* h, const double* basis_ddn) {
   });
 }
 
+pfv_status pfv_mpsa_set_subface_bc(pfv_ctx* h, const uint8_t* bc_dir_bits_sub, const uint8_t* bc_neu_bits_sub,
+                                   const uint8_t* bc_rob_bits_sub, const double* robin_weight_dds) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_mpsa_params, "pfv_mpsa_set_params first");
+    h->mpsa_subface_bc = false;
+    h->have_mpsa_numeric = h->have_mech_system = false;
+    if (!bc_dir_bits_sub) return;  // back to conditions per face
+    require(bc_neu_bits_sub != nullptr, "null parameter array");
+    require(!h->have_mpsa_basis, "conditions per sub-face in a face-wise basis are not covered");
+    require(h->biot_nalpha == 0, "conditions per sub-face with Biot coupling terms are not covered");
+    auto s = h->stream;
+    if (!h->have_topology) {  // the sub-face count is known from the topology
+      pfv::build_topology(*h);
+      pfv::build_symbolic(*h);
+      h->tpfa_mode = false;
+      h->have_mpsa_symbolic = false;
+      h->have_sub_symbolic = h->have_mpsa_sub_symbolic = false;
+      h->have_numeric = h->have_system = false;
+    }
+    const size_t nsf = (size_t)h->nsf, n2 = (size_t)h->nd * h->nd;
+    upload(h->bc_dirbits_sub, bc_dir_bits_sub, nsf, s);
+    upload(h->bc_neubits_sub, bc_neu_bits_sub, nsf, s);
+    h->have_mpsa_robin_sub = bc_rob_bits_sub != nullptr;
+    if (bc_rob_bits_sub) {
+      upload(h->bc_robbits_sub, bc_rob_bits_sub, nsf, s);
+      if (robin_weight_dds) {
+        upload(h->mpsa_robw_sub, robin_weight_dds, n2 * nsf, s);
+      } else {
+        std::vector<double> eye(n2 * nsf, 0.0);
+        for (int i = 0; i < h->nd; ++i)
+          for (size_t f = 0; f < nsf; ++f) eye[((size_t)h->nd * i + i) * nsf + f] = 1.0;
+        upload(h->mpsa_robw_sub, eye.data(), n2 * nsf, s);
+      }
+    }
+    h->mpsa_subface_bc = true;
+  });
+}
+
 pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags) {
   return guarded(h, [&] {
     require(h->have_grid && h->have_mpsa_params, "grid and MPSA parameters must be set before discretize");
@@ -767,6 +806,7 @@ pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags) {
       h->stats.symbolic_ms = tm.stop(s);
       h->tpfa_mode = false;
       h->have_mpsa_symbolic = false;
+      h->have_sub_symbolic = h->have_mpsa_sub_symbolic = false;
       h->have_numeric = h->have_system = false;
     }
     if (!h->have_mpsa_symbolic) {
@@ -776,11 +816,18 @@ pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags) {
       h->have_biot_symbolic = false;
     }
     if (h->biot_nalpha > 0 && !h->have_biot_symbolic) pfv::biot_symbolic(*h);
+    if (h->mpsa_subface_bc && !h->have_mpsa_sub_symbolic) {
+      require(h->biot_nalpha == 0, "conditions per sub-face with Biot coupling terms are not covered");
+      tm.start(s);
+      pfv::mpsa_subface_symbolic(*h);
+      h->stats.symbolic_ms += tm.stop(s);
+    }
     tm.start(s);
     pfv::mpsa_run_node_kernel(*h);
     h->stats.node_ms = tm.stop(s);
     tm.start(s);
     pfv::mpsa_run_face_kernel(*h);
+    if (h->mpsa_subface_bc) pfv::mpsa_run_subface_kernel(*h);
     h->stats.face_ms = tm.stop(s);
     h->have_mpsa_numeric = true;
     h->rows_complete_m = true;
@@ -796,6 +843,7 @@ pfv_status pfv_mpsa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces
     require(n_faces >= 0 && (n_faces == 0 || faces), "bad face list");
     require(!keep_other_rows || h->rows_complete_m,
             "update of a discretization that was never computed on this handle");
+    require(!h->mpsa_subface_bc, "partial discretization with conditions per sub-face is not covered");
     for (int64_t i = 0; i < n_faces; ++i)
       require(faces[i] >= 0 && faces[i] < h->nf, "face index out of range");
     auto s = h->stream;
@@ -806,6 +854,7 @@ pfv_status pfv_mpsa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces
       pfv::build_symbolic(*h);
       h->tpfa_mode = false;
       h->have_mpsa_symbolic = false;
+      h->have_sub_symbolic = h->have_mpsa_sub_symbolic = false;
       h->have_numeric = h->have_system = false;
     }
     if (!h->have_mpsa_symbolic) {
@@ -968,6 +1017,7 @@ pfv_status pfv_biot_get_matrix(pfv_ctx* h, int term, int key, int32_t* indptr, i
 pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* source) {
   return guarded(h, [&] {
     require(h->have_mpsa_numeric, "pfv_mpsa_discretize first");
+    require(!h->mpsa_subface_bc, "stress has sub-face rows (conditions per sub-face): collapse it before assembling");
     require(bc_values != nullptr, "bc_values is required");
     auto s = h->stream;
     const size_t nfd = (size_t)h->nf * h->nd, ncd = (size_t)h->nc * h->nd;

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from .grid import grid_to_raw
-from .mpfa import determine_eta
+from .mpfa import determine_eta, sps_nnz, subface_order
 from .partial import active_indices
 from .params import DISCRETIZATION_MATRICES, PARAMETERS
 
@@ -74,9 +74,30 @@ class Mpsa:
             raise NotImplementedError("per-sub-face eta is not covered for MPSA yet")
         ctx = self.context(sd)
         is_rob = getattr(bnd, "is_rob", None)
-        ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta),
-                            is_rob=is_rob, robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None,
-                            basis=basis)
+        nsub = sps_nnz(sd.face_nodes)
+        subface = np.asarray(bnd.is_dir).shape[1] == nsub and nsub != sd.num_faces
+        order = None
+        if subface:
+            # conditions per sub-face (mpsa.py:712-720): they follow the storage order of the caller's face_nodes,
+            # the device numbers sub-faces by the sorted CSC arrays
+            if partial or update:
+                raise NotImplementedError("partial discretization with conditions per sub-face is not covered")
+            if basis is not None and not np.array_equal(
+                    np.asarray(basis), np.tile(np.eye(sd.dim)[:, :, None], (1, 1, nsub))):
+                raise NotImplementedError("conditions per sub-face in a face-wise basis are not covered")
+            order = subface_order(sd.face_nodes)
+            nd, nf = sd.dim, sd.num_faces
+            ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, np.zeros((nd, nf), bool), np.ones((nd, nf), bool),
+                                float(eta))  # per-face placeholders; the sub-face arrays take over
+            rob_sub = None if is_rob is None else np.asarray(is_rob, bool)[:, order]
+            rw = getattr(bnd, "robin_weight", None)
+            ctx.mpsa_set_subface_bc(np.asarray(bnd.is_dir, bool)[:, order], np.asarray(bnd.is_neu, bool)[:, order],
+                                    rob_sub, None if (rob_sub is None or rw is None) else np.asarray(rw, float)[:, :, order])
+        else:
+            ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta),
+                                is_rob=is_rob,
+                                robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None,
+                                basis=basis)
         rows = None
         try:
             if partial:
@@ -97,6 +118,17 @@ class Mpsa:
             raise
         for name, which in _KEYS:
             new = ctx.matrix(which, rows=rows)
+            if order is not None and not np.array_equal(order, np.arange(order.size)):
+                # sub-face blocks from the device's numbering back to the caller's (rows of stress / bound_stress,
+                # columns of the two boundary matrices)
+                import scipy.sparse as sps
+
+                blk = (sd.dim * order[:, None] + np.arange(sd.dim)[None, :]).ravel()  # device -> caller
+                coo = sps.coo_matrix(new)
+                r = blk[coo.row] if name in ("stress", "bound_stress") else coo.row
+                c = blk[coo.col] if name in ("bound_stress", "bound_displacement_face") else coo.col
+                new = sps.csr_matrix((coo.data, (r, c)), shape=new.shape)
+                new.sort_indices()
             if partial and update and rows is not None and name in md:
                 old = md[name].tolil()
                 old[rows] = new[rows]

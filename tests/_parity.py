@@ -384,6 +384,76 @@ def check_mpsa_golden_case(lib, name: str):
     ctx.close()
 
 
+def check_mpsa_subface_case(lib, name: str, scramble: bool = False):
+    """Conditions per sub-face (mpsa.py:712-720, 752-754, 780-781, 1127-1138): through the C ABI against the
+    oracle (exact pattern) and the matrices the reference produced; through the host mirror with the
+    caller's face_nodes stored unsorted (``scramble``: the sub-face numbering then differs from the device's)."""
+    from tests._golden import MpsaSubfaceCase
+
+    c = MpsaSubfaceCase(name)
+    nd = c.grid["dim"]
+    ora = so.discretize(c.grid, c.stiffness, c.bc)
+    if not scramble:
+        ctx = pa.Context(0, lib)
+        ctx.set_grid(c.grid)
+        nf = c.grid["face_centers"].shape[1]
+        ctx.mpsa_set_params(c.stiffness, c.grid["cell_volumes"], np.zeros((nd, nf), bool), np.ones((nd, nf), bool),
+                            mo.default_eta(c.grid["name"]))
+        ctx.mpsa_set_subface_bc(c.bc["is_dir"], c.bc["is_neu"], c.bc["is_rob"], c.bc["robin_weight"])
+        ctx.mpsa_discretize()
+        for k in MPSA_KEYS:
+            M = ctx.matrix(MPSA_WHICH[k])
+            assert M.shape == c.ref[k].shape, (name, k, M.shape)
+            assert M.indices.dtype == np.int32 and M.has_sorted_indices
+            assert np.array_equal(M.indptr, ora[k].indptr), (name, k)
+            assert np.array_equal(M.indices, ora[k].indices), (name, k)
+            assert rel_max_err(M, ora[k]) < TOL, (name, k)
+            assert rel_max_err(M, c.ref[k]) < TOL, (name, k)
+        with pytest.raises(pa._lib.PorefvError, match="sub-face rows"):
+            ctx.mpsa_assemble(np.zeros(nd * nf), None)
+        # back to conditions per face on the same handle
+        ctx.mpsa_set_params(c.stiffness, c.grid["cell_volumes"], np.ones((nd, nf), bool), np.zeros((nd, nf), bool),
+                            mo.default_eta(c.grid["name"]))
+        ctx.mpsa_discretize()
+        assert ctx.matrix(MPSA_WHICH["stress"]).shape == (nd * nf, nd * c.grid["cell_centers"].shape[1])
+        ctx.close()
+        return
+    # host mirror, unsorted storage of face_nodes
+    import scipy.sparse as sps
+
+    g = pa.grid_from_raw(c.grid)
+    fn = sps.csc_matrix(g.face_nodes)
+    rng = np.random.default_rng(11)
+    ind, dat = fn.indices.copy(), fn.data.copy()
+    perm = np.arange(ind.size)
+    for f in range(fn.shape[1]):
+        a, b = fn.indptr[f], fn.indptr[f + 1]
+        perm[a:b] = a + rng.permutation(b - a)
+    g.face_nodes = sps.csc_matrix((dat[perm], ind[perm], fn.indptr), shape=fn.shape)
+    # conditions in the caller's (scrambled) sub-face order; perm[p_caller] = sorted position
+    bc = pa.BoundaryConditionVectorial(g)
+    bc.is_dir, bc.is_neu, bc.is_rob = c.bc["is_dir"][:, perm], c.bc["is_neu"][:, perm], c.bc["is_rob"][:, perm]
+    bc.robin_weight = c.bc["robin_weight"][:, :, perm]
+    bc.basis = np.tile(np.eye(nd)[:, :, None], (1, 1, perm.size))
+    bc.num_faces = perm.size
+    C = pa.FourthOrderTensor.from_values(c.stiffness) if hasattr(pa.FourthOrderTensor, "from_values") else None
+    if C is None:
+        C = pa.FourthOrderTensor(np.ones(g.num_cells), np.ones(g.num_cells))
+        C.values = c.stiffness
+    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc})
+    pa.Mpsa("mechanics", library=lib).discretize(g, data)
+    md = data[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    blk = (nd * perm[:, None] + np.arange(nd)[None, :]).ravel()  # caller block -> sorted block
+    for k in MPSA_KEYS:
+        ref = c.ref[k]
+        if k in ("stress", "bound_stress"):
+            ref = ref[blk]
+        if k in ("bound_stress", "bound_displacement_face"):
+            ref = ref[:, blk]
+        assert md[k].shape == ref.shape
+        assert rel_max_err(md[k], ref.tocsr()) < TOL, (name, k)
+
+
 def check_mpsa_known_answer(lib, key: str):
     """The reference's golden displacement / traction vectors (test_mpsa.py:1296-1323)."""
     c = MpsaCase("mpsa_known_" + key)

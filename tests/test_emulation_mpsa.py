@@ -151,3 +151,9 @@ def test_mpsa_patch_parity_machinery_small(lib):
     """The all-matrices patch test of the GPU suite on a small grid (host emulation)."""
     out = P.mpsa_patch_parity_all_matrices(lib, 4, n_random=1)
     assert out["patches"] == 15 and out["rows_checked"] > 100
+
+
+@pytest.mark.parametrize("name", ["mpsasub_cart2d_4x3", "mpsasub_tri2d_3x3_rob", "mpsasub_tet3d_2x2x2"])
+@pytest.mark.parametrize("scramble", [False, True])
+def test_boundary_conditions_per_subface(lib, name, scramble):
+    P.check_mpsa_subface_case(lib, name, scramble)

@@ -118,3 +118,9 @@ def test_config_c3_all_four_matrices_on_patches(lib):
     (box corners where roller / traction / free faces meet, side centres, random cells)."""
     out = P.mpsa_patch_parity_all_matrices(lib, 44)
     assert out["patches"] >= 18 and out["rows_checked"] > 1000
+
+
+@pytest.mark.parametrize("name", ["mpsasub_cart2d_4x3", "mpsasub_tri2d_3x3_rob", "mpsasub_tet3d_2x2x2"])
+@pytest.mark.parametrize("scramble", [False, True])
+def test_boundary_conditions_per_subface(lib, name, scramble):
+    P.check_mpsa_subface_case(lib, name, scramble)
