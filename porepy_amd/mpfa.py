@@ -154,7 +154,7 @@ def estimate_device_bytes(sd) -> int:
     return int(1.15 * (tables + patterns + values + topo + grid + staging + solver))
 
 
-def plan_subproblems(sd, partition_arguments, free_bytes) -> int:
+def plan_subproblems(sd, partition_arguments, free_bytes, need=None, what: str = "MPFA") -> int:
     """Number of overlapping sub-grids the discretization is done in (reference: mpfa.py:157-161 with
     _fvutils.parse_partition_arguments, the peak-memory estimate of mpfa.py:1315-1355 and
     _fvutils.subproblems, _fvutils.py:414-539).  ``num_subproblems`` is taken as given; ``max_memory`` (bytes)
@@ -164,7 +164,8 @@ def plan_subproblems(sd, partition_arguments, free_bytes) -> int:
     import math
 
     pa = dict(partition_arguments or {})
-    need = estimate_device_bytes(sd)
+    if need is None:
+        need = estimate_device_bytes(sd)
     if "num_subproblems" in pa:
         n = max(1, int(pa["num_subproblems"]))
     elif "max_memory" in pa:
@@ -176,8 +177,8 @@ def plan_subproblems(sd, partition_arguments, free_bytes) -> int:
     n = min(n, max(1, sd.num_cells))
     if n > 1:
         logging.getLogger("porepy_amd").info(
-            "MPFA on %d cells in %d overlapping pieces (estimated %.1f GB in one piece, %s GB free)", sd.num_cells, n,
-            need / 1e9, "?" if free_bytes is None else f"{free_bytes / 1e9:.1f}")
+            "%s on %d cells in %d overlapping pieces (estimated %.1f GB in one piece, %s GB free)", what, sd.num_cells,
+            n, need / 1e9, "?" if free_bytes is None else f"{free_bytes / 1e9:.1f}")
     return n
 
 

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from .grid import grid_to_raw
-from .mpfa import determine_eta, sps_nnz, subface_order
+from .mpfa import determine_eta, estimate_device_bytes, partition_cells, plan_subproblems, sps_nnz, subface_order
 from .partial import active_indices
 from .params import DISCRETIZATION_MATRICES, PARAMETERS
 
@@ -35,6 +35,8 @@ class Mpsa:
         self.bound_displacement_cell_matrix_key = "bound_displacement_cell"
         self.bound_displacement_face_matrix_key = "bound_displacement_face"
         self._contexts: dict = {}
+        self._split: dict = {}  # id(sd) -> (sd, A) of a grid discretized in pieces (no whole-grid handle exists)
+        self._probe = None
 
     def ndof(self, sd) -> int:
         return sd.dim * sd.num_cells
@@ -72,10 +74,25 @@ class Mpsa:
             eta = determine_eta(sd)
         elif np.asarray(eta).size != 1:
             raise NotImplementedError("per-sub-face eta is not covered for MPSA yet")
-        ctx = self.context(sd)
         is_rob = getattr(bnd, "is_rob", None)
         nsub = sps_nnz(sd.face_nodes)
         subface = np.asarray(bnd.is_dir).shape[1] == nsub and nsub != sd.num_faces
+        self._split.pop(id(sd), None)
+        ent = self._contexts.get(id(sd))
+        if not (ent is not None and ent[0] is sd and ent[1].has_mpsa_discretization):
+            if self._probe is None:
+                self._probe = _lib.Context(self.device, self._library)
+            # the expanded rows of an interaction region are nd x as wide as the MPFA tables, the matrices nd^2 x
+            nparts = plan_subproblems(sd, pd.get("partition_arguments"), self._probe.free_device_bytes(),
+                                      need=sd.dim * estimate_device_bytes(sd), what="MPSA")
+            if nparts > 1:
+                if not (partial or update or subface):
+                    return self._discretize_in_pieces(sd, data, nparts, float(eta), basis)
+                import logging
+
+                logging.getLogger("porepy_amd").warning(
+                    "partition_arguments: partial updates and conditions per sub-face are discretized in one piece")
+        ctx = self.context(sd)
         order = None
         if subface:
             # conditions per sub-face (mpsa.py:712-720): they follow the storage order of the caller's face_nodes,
@@ -137,6 +154,112 @@ class Mpsa:
         pd["active_cells"] = active_cells
         pd["active_faces"] = active_faces
 
+    def _discretize_in_pieces(self, sd, data: dict, nparts: int, eta: float, basis) -> None:
+        """Memory-bounded discretization (mpsa.py:201-207, 245-380 with _fvutils.subproblems, _fvutils.py:414-539):
+        as ``Mpfa._discretize_in_pieces`` -- cell partition, one node-ring of overlap, every piece discretized on
+        the device on its own, rows of the faces of its own cells merged on the host (faces between two pieces
+        are computed by both and averaged), one piece resident at a time; the system matrix div_nd @ stress comes
+        from the pieces too."""
+        import scipy.sparse as sps
+
+        from .distributed import extract_subdomain
+
+        pd = data[PARAMETERS][self.keyword]
+        md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
+        raw = grid_to_raw(sd)
+        nd, nc, nf = sd.dim, sd.num_cells, sd.num_faces
+        Cv = np.asarray(pd["fourth_order_tensor"].values, dtype=float)
+        bnd = pd["bc"]
+        is_dir, is_neu = np.asarray(bnd.is_dir, bool), np.asarray(bnd.is_neu, bool)
+        is_rob = getattr(bnd, "is_rob", None)
+        is_rob = None if is_rob is None or not np.any(is_rob) else np.asarray(is_rob, bool)
+        robw = getattr(bnd, "robin_weight", None)
+        owner = partition_cells(sd, nparts)
+        ncols = {"stress": nd * nc, "bound_stress": nd * nf, "bound_displacement_cell": nd * nc,
+                 "bound_displacement_face": nd * nf}
+        acc = {name: ([], [], []) for name, _ in _KEYS}
+        sysacc = ([], [], [])
+        count = np.zeros(nf, dtype=np.int64)
+        comp = np.arange(nd)[None, :]
+        for r in range(nparts):
+            if not np.any(owner == r):
+                continue
+            lp = extract_subdomain(raw, owner, r)
+            ctx = _lib.Context(self.device, self._library)
+            try:
+                ctx.set_grid(lp.raw)
+                art = lp.artificial_boundary
+                ldir, lneu = is_dir[:, lp.face_gid].copy(), is_neu[:, lp.face_gid].copy()
+                ldir[:, art], lneu[:, art] = False, True  # never touches a node of an own cell
+                lrob = None
+                if is_rob is not None:
+                    lrob = is_rob[:, lp.face_gid].copy()
+                    lrob[:, art] = False
+                ctx.mpsa_set_params(np.ascontiguousarray(Cv[:, :, lp.cell_gid]), lp.raw["cell_volumes"], ldir, lneu, eta,
+                                    is_rob=lrob,
+                                    robin_weight=None if (lrob is None or robw is None) else
+                                    np.ascontiguousarray(np.asarray(robw, float)[:, :, lp.face_gid]),
+                                    basis=None if basis is None else np.ascontiguousarray(np.asarray(basis, float)[:, :, lp.face_gid]))
+                try:
+                    ctx.mpsa_discretize(rebuild_topology=True)
+                except _lib.PorefvError as e:
+                    if e.status == 1:
+                        raise ValueError("Error in inversion of local linear systems") from e
+                    if e.status == 2:
+                        raise AssertionError(e.message) from e
+                    raise
+                cfp = lp.raw["cf_indptr"]
+                own_faces = np.unique(lp.raw["cf_indices"][: cfp[lp.n_own]])
+                count[lp.face_gid[own_faces]] += 1
+                lrows = (nd * own_faces[:, None] + comp).ravel()
+                grows = (nd * lp.face_gid[own_faces][:, None] + comp).ravel()
+                ccol = (nd * lp.cell_gid[:, None] + comp).ravel()
+                fcol = (nd * lp.face_gid[:, None] + comp).ravel()
+                for name, which in _KEYS:
+                    M = ctx.matrix_rows(which, lrows).tocoo()
+                    cmap = fcol if ncols[name] == nd * nf else ccol
+                    rr, cc, vv = acc[name]
+                    rr.append(grows[M.row])
+                    cc.append(cmap[M.col])
+                    vv.append(M.data)
+                ctx.mpsa_assemble(np.zeros(nd * lp.face_gid.size), None)
+                S = ctx.matrix_rows(_lib.MAT_MECH_SYSTEM, np.arange(nd * lp.n_own)).tocoo()
+                sysacc[0].append(ccol[S.row])
+                sysacc[1].append(ccol[S.col])
+                sysacc[2].append(S.data)
+            finally:
+                ctx.close()
+        scale = np.repeat(1.0 / np.maximum(count, 1), nd)
+        for name, _ in _KEYS:
+            rr, cc, vv = (np.concatenate(x) if x else np.zeros(0) for x in acc[name])
+            M = sps.coo_matrix((vv * scale[rr.astype(np.int64)], (rr, cc)), shape=(nd * nf, ncols[name])).tocsr()
+            M.sum_duplicates()
+            M.sort_indices()
+            md[name] = M
+        A = sps.coo_matrix((np.concatenate(sysacc[2]), (np.concatenate(sysacc[0]), np.concatenate(sysacc[1]))),
+                           shape=(nd * nc, nd * nc)).tocsr()
+        A.sum_duplicates()
+        A.sort_indices()
+        self._split[id(sd)] = (sd, A)
+        self._contexts.pop(id(sd), None)
+        pd["active_cells"] = np.arange(nc)
+        pd["active_faces"] = np.arange(nf)
+
+    def _split_system(self, sd, data: dict):
+        """(A, b) of a grid discretized in pieces: A from the pieces' device-side div_nd @ stress, b from the merged
+        bound_stress (one host SpMV, mpsa.py:486-529)."""
+        import scipy.sparse as sps
+
+        pd = data[PARAMETERS][self.keyword]
+        md = data[DISCRETIZATION_MATRICES][self.keyword]
+        nd = sd.dim
+        div = sps.kron(sd.cell_faces.T.tocsr(), sps.identity(nd), format="csr")
+        b = -(div @ (md["bound_stress"] @ np.asarray(pd["bc_values"], dtype=float)))
+        src = pd.get("source", None)
+        if src is not None:
+            b = b + np.asarray(src, dtype=float)
+        return self._split[id(sd)][1], b
+
     def update_discretization(self, sd, data: dict) -> None:
         """Rediscretize around ``data["update_discretization"]["modified_cells" / "modified_faces"]``,
         keep every other row (mpsa.py:418-487 via _fvutils.partial_update_discretization)."""
@@ -180,12 +303,22 @@ class Mpsa:
 
     def assemble_matrix_rhs(self, sd, data: dict):
         """A = div_nd @ stress, b = -div_nd @ bound_stress @ bc_values + source (mpsa.py:486-529)."""
+        sp = self._split.get(id(sd))
+        if sp is not None and sp[0] is sd:
+            return self._split_system(sd, data)
         ctx = self._assemble(sd, data)
         n = sd.dim * sd.num_cells
         return ctx.matrix(_lib.MAT_MECH_SYSTEM), ctx.active_rhs(n)
 
     def solve(self, sd, data: dict, method: str = "bicgstab", rtol: float = 1e-12, maxit: int = 50000, x0=None,
               restart: int = 0, precond: str = "jacobi"):
+        sp = self._split.get(id(sd))
+        if sp is not None and sp[0] is sd:
+            from .solvers import solve_csr
+
+            A, b = self._split_system(sd, data)
+            return solve_csr(A, b, method=method, rtol=rtol, maxit=maxit, restart=restart, device=self.device,
+                             library=self._library, precond=precond)
         ctx = self._assemble(sd, data)
         return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, n=sd.dim * sd.num_cells, restart=restart,
                          precond=precond)

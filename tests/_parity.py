@@ -1496,3 +1496,60 @@ def split_matches_one_piece(lib, g, K, bc, bv, split_kwargs, monkeypatch=None, f
     xo = spla.spsolve(A1.tocsc(), b1)
     assert info["converged"] and np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
     assert np.array_equal(many[pa.PARAMETERS]["flow"]["active_faces"], np.arange(g.num_faces))
+
+
+def mpsa_split_matches_one_piece(lib, g, C, bc, bv, split_kwargs, source=None):
+    """Mpsa with partition_arguments (mpsa.py:201-207, 245-380): merged matrices, system and solution equal the
+    one-piece discretization."""
+    def mk(**extra):
+        p = {"fourth_order_tensor": C, "bc": bc, "bc_values": bv, **extra}
+        if source is not None:
+            p["source"] = source
+        return pa.initialize_data({}, "mechanics", p)
+
+    one = mk()
+    d1 = pa.Mpsa("mechanics", library=lib)
+    d1.discretize(g, one)
+    A1, b1 = d1.assemble_matrix_rhs(g, one)
+    many = mk(**split_kwargs)
+    d2 = pa.Mpsa("mechanics", library=lib)
+    d2.discretize(g, many)
+    assert id(g) in d2._split and id(g) not in d2._contexts
+    m1, m2 = one[pa.DISCRETIZATION_MATRICES]["mechanics"], many[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    for name in MPSA_KEYS:
+        ref = m1[name]
+        assert m2[name].shape == ref.shape
+        assert abs(m2[name] - ref).max() <= 1e-11 * max(abs(ref).max(), 1e-300), name
+    A2, b2 = d2.assemble_matrix_rhs(g, many)
+    assert abs(A2 - A1).max() <= 1e-11 * abs(A1).max()
+    assert np.linalg.norm(b2 - b1) <= 1e-11 * max(np.linalg.norm(b1), 1e-300)
+    x, info = d2.solve(g, many, rtol=1e-12)
+    xo = spla.spsolve(A1.tocsc(), b1)
+    assert info["converged"] and np.linalg.norm(x - xo) <= 1e-7 * np.linalg.norm(xo)
+
+
+def mpsa_pieces_case(lib, dim: int):
+    rng = np.random.default_rng(4)
+    if dim == 3:
+        g = pa.StructuredTetrahedralGrid([3, 3, 3], [1.0, 1.0, 1.0])
+        g.compute_geometry()
+        g = pa.perturb_interior_nodes(g, 0.03, seed=2)
+    else:
+        g = pa.CartGrid([7, 6], [1.0, 1.0])
+        g.compute_geometry()
+    nc, nf = g.num_cells, g.num_faces
+    C = pa.FourthOrderTensor(1 + rng.random(nc), 0.5 + rng.random(nc))
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    bot = bf[g.face_centers[dim - 1, bf] < 1e-9]
+    bc.is_dir[:, bot] = True
+    bc.is_neu[:, bot] = False
+    west = bf[g.face_centers[0, bf] < 1e-9]
+    bc.is_dir[0, west] = True
+    bc.is_neu[0, west] = False
+    bv = np.zeros((dim, nf))
+    top = bf[g.face_centers[dim - 1, bf] > 1 - 1e-9]
+    bv[dim - 1, top] = -g.face_areas[top]
+    bv[0, bot] = 0.01 * g.face_centers[0, bot]
+    mpsa_split_matches_one_piece(lib, g, C, bc, bv.ravel("F"), dict(partition_arguments={"num_subproblems": 3}),
+                                 source=0.01 * rng.standard_normal(dim * nc))

@@ -157,3 +157,8 @@ def test_mpsa_patch_parity_machinery_small(lib):
 @pytest.mark.parametrize("scramble", [False, True])
 def test_boundary_conditions_per_subface(lib, name, scramble):
     P.check_mpsa_subface_case(lib, name, scramble)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_partition_arguments_discretize_in_pieces(lib, dim):
+    P.mpsa_pieces_case(lib, dim)

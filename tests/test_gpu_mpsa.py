@@ -124,3 +124,8 @@ def test_config_c3_all_four_matrices_on_patches(lib):
 @pytest.mark.parametrize("scramble", [False, True])
 def test_boundary_conditions_per_subface(lib, name, scramble):
     P.check_mpsa_subface_case(lib, name, scramble)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_partition_arguments_discretize_in_pieces(lib, dim):
+    P.mpsa_pieces_case(lib, dim)
