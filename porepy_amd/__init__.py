@@ -7,7 +7,7 @@ reached through the C ABI of ``include/porefv.h``.
 """
 from . import _lib
 from ._lib import Context, PorefvError
-from .grid import (CartGrid, Grid, StructuredTetrahedralGrid, StructuredTriangleGrid, grid_from_raw,
+from .grid import (CartGrid, Grid, StructuredTetrahedralGrid, StructuredTriangleGrid, TetrahedralGrid, grid_from_raw,
                    grid_to_raw, perturb_interior_nodes)
 from .mpfa import Mpfa, as_porepy_discretization, determine_eta
 from .mpsa import Mpsa, as_porepy_mpsa
@@ -20,7 +20,7 @@ from .params import (DISCRETIZATION_MATRICES, PARAMETERS, BoundaryCondition, Bou
 
 __all__ = [
     "Context", "PorefvError", "Grid", "CartGrid", "StructuredTriangleGrid",
-    "StructuredTetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "grid_from_raw", "Mpfa",
+    "StructuredTetrahedralGrid", "TetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "grid_from_raw", "Mpfa",
     "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition", "Mpsa",
     "FourthOrderTensor", "BoundaryConditionVectorial",
     "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa", "DifferentiableTpfa", "as_porepy_ad_tpfa_flux", "Biot", "as_porepy_mpsa", "as_porepy_biot",

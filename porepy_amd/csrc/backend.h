@@ -577,6 +577,42 @@ __global__ void __launch_bounds__(T) k_block_for(int64_t n, size_t lds_bytes, F 
   }
 }
 #endif
+// The same, for work items whose scratch does not fit the LDS (MPSA interaction regions of nodes where more
+// than ~36 faces meet): every resident workgroup works in its own slice of a global-memory buffer instead.
+// Slow (every access is an L2 round trip) but it removes the size limit; only the few oversized items of a
+// launch take this path.  The 128 bytes for cross-wavefront reductions stay in LDS.
+#ifndef PFV_EMULATE
+template <int T, class F>
+__global__ void __launch_bounds__(T) k_block_for_global(int64_t n, size_t bytes, char* scratch, F f) {
+  extern __shared__ __attribute__((aligned(16))) char pfv_lds[];
+  char* mine = scratch + (size_t)blockIdx.x * bytes;
+  for (int64_t b = blockIdx.x; b < n; b += gridDim.x) {
+    WaveCtx w{b, mine, (int)threadIdx.x, T, pfv_lds};
+    f(w);
+    __syncthreads();
+  }
+}
+#endif
+template <int T = 256, class F>
+inline void block_for_global(stream_t s, int64_t n, size_t bytes, Buf<char>& scratch, F f) {
+  if (n <= 0) return;
+  bytes = (bytes + 255) & ~size_t(255);
+#ifdef PFV_EMULATE
+  (void)s;
+  (void)scratch;
+  std::vector<double> mem((bytes + 7) / 8 + 2);
+  for (int64_t b = 0; b < n; ++b) {
+    WaveCtx w{b, reinterpret_cast<char*>(mem.data()), 0, 1, nullptr};
+    f(w);
+  }
+#else
+  const int64_t blocks = n < 256 ? n : 256;
+  char* buf = scratch.ensure((size_t)blocks * bytes);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_for_global<T, F>), dim3((unsigned)blocks), dim3(T), 128, s, n, bytes, buf, f);
+  PFV_HIP_CHECK(hipGetLastError());
+#endif
+}
+
 template <int T = 256, class F>
 inline void block_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
   if (n <= 0) return;

@@ -357,6 +357,23 @@ class StructuredTetrahedralGrid(Grid):
         self.__dict__.update(g.__dict__)
 
 
+class TetrahedralGrid(Grid):
+    """Unstructured tetrahedral grid from points (3, Np) and, optionally, the (Nc, 4) node ids of the cells
+    (Delaunay triangulation of the points otherwise), as the reference's ``pp.TetrahedralGrid(p, tet)``
+    (grids/simplex.py:206-330).  Nodes of such grids are met by any number of cells."""
+
+    def __init__(self, p, tet=None, name: str = "TetrahedralGrid"):
+        pts = np.asarray(p, dtype=float)
+        if tet is None:
+            import scipy.spatial
+
+            tet = scipy.spatial.Delaunay(pts.T).simplices
+        cells = np.sort(np.asarray(tet, dtype=np.int64).reshape(-1, 4), axis=1)
+        g = _simplex_grid(3, pts, cells, name)
+        _fix_simplex_signs(g)
+        self.__dict__.update(g.__dict__)
+
+
 def perturb_interior_nodes(g: Grid, rate: float, seed: int = 1) -> Grid:
     """nodes += (U(0,1) - 0.5) * rate on nodes strictly inside the bounding box, then
     recompute geometry (the synthetic 'unstructured-like' grids of SURVEY 8(d))."""

@@ -1553,3 +1553,45 @@ def mpsa_pieces_case(lib, dim: int):
     bv[0, bot] = 0.01 * g.face_centers[0, bot]
     mpsa_split_matches_one_piece(lib, g, C, bc, bv.ravel("F"), dict(partition_arguments={"num_subproblems": 3}),
                                  source=0.01 * rng.standard_normal(dim * nc))
+
+
+def hub_tetrahedral_grid(n_ring: int = 40, seed: int = 3):
+    """Delaunay grid with one node met by ~40 cells / ~60 faces (more than any lattice subdivision has)."""
+    rng = np.random.default_rng(seed)
+    u = rng.standard_normal((3, n_ring))
+    u /= np.linalg.norm(u, axis=0)
+    pts = np.hstack([np.zeros((3, 1)), 0.5 * u, rng.standard_normal((3, 30)) / 2]) + 0.5
+    g = pa.TetrahedralGrid(pts)
+    g.compute_geometry()
+    return g
+
+
+def mpsa_large_interaction_region(lib):
+    """An unstructured grid whose hub node has a 3 x 63 = 189-unknown interaction region: too large for the LDS
+    of a CU (the limit is ~36 faces per node), so it is worked on in global-memory scratch; all four matrices
+    against the oracle."""
+    g = hub_tetrahedral_grid()
+    raw = pa.grid_to_raw(g)
+    nsf_node = np.bincount(raw["fn_indices"], minlength=g.num_nodes)
+    assert nsf_node.max() > 40
+    nd, nc, nf = 3, g.num_cells, g.num_faces
+    rng = np.random.default_rng(8)
+    C = pa.FourthOrderTensor(1 + rng.random(nc), 0.5 + rng.random(nc))
+    bf = g.get_all_boundary_faces()
+    is_dir = np.zeros((nd, nf), bool)
+    is_neu = np.zeros((nd, nf), bool)
+    is_neu[:, bf] = True
+    low = bf[g.face_centers[2, bf] < np.median(g.face_centers[2, bf])]
+    is_dir[:, low] = True
+    is_neu[:, low] = False
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(raw)
+    eta = mo.default_eta(raw["name"])
+    ctx.mpsa_set_params(C.values, g.cell_volumes, is_dir, is_neu, eta)
+    ctx.mpsa_discretize()
+    ora = so.discretize(raw, C.values, {"is_dir": is_dir, "is_neu": is_neu}, eta=eta)
+    for k in MPSA_KEYS:
+        M = ctx.matrix(MPSA_WHICH[k])
+        assert np.array_equal(M.indptr, ora[k].indptr) and np.array_equal(M.indices, ora[k].indices), k
+        assert rel_max_err(M, ora[k]) < 1e-8, (k, rel_max_err(M, ora[k]))  # sliver cells: conditioning, not a bug
+    ctx.close()

@@ -162,3 +162,7 @@ def test_boundary_conditions_per_subface(lib, name, scramble):
 @pytest.mark.parametrize("dim", [2, 3])
 def test_partition_arguments_discretize_in_pieces(lib, dim):
     P.mpsa_pieces_case(lib, dim)
+
+
+def test_interaction_region_larger_than_lds(lib):
+    P.mpsa_large_interaction_region(lib)
