@@ -340,6 +340,11 @@ def bench_operator_api(pa, lp, Kvals, flags, bv, src, eta, device_index: int):
 
 
 def main():
+    # stdout carries exactly one line, the JSON record: everything else this process or its libraries print
+    # (RCCL writes a version banner to the C-level stdout when a communicator is created) goes to stderr
+    sys.stdout.flush()
+    record_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -679,7 +684,8 @@ def main():
         }
         if args.phases:
             print(json.dumps(st, indent=1), file=sys.stderr)
-        print(json.dumps(line))
+        record_out.write(json.dumps(line) + "\n")
+        record_out.flush()
     if dist is not None:
         dist.destroy_process_group()
 
