@@ -179,6 +179,7 @@ struct pfv_ctx_impl {
   Buf<double> mpsa_basis;            // [nd*nd][Nf] boundary basis (BoundaryConditionVectorial.basis)
   bool have_mpsa_basis = false;
   Buf<char> mpsa_scratch;            // global-memory work space of interaction regions too large for the LDS
+  Buf<long long> mpsa_clk;           // timing lab (PFV_MPSA_CLOCK): s_memtime stamps of one workgroup
   // conditions per sub-face (mpsa.py:712-720): flags / weights per sub-face replace the per-face ones, stress and
   // bound_stress keep sub-face rows, the boundary matrices sub-face columns
   bool mpsa_subface_bc = false, have_mpsa_sub_symbolic = false;
