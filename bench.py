@@ -547,7 +547,8 @@ def main():
                   "frac_on_reference_formulation_flops": ref_flops / (node_ms * 1e-3) / fp64_peak,
                   "bytes_written_per_launch": 8.0 * st["node_table_doubles"],
                   "written_GBs": 8.0 * st["node_table_doubles"] / (node_ms * 1e-3) / 1e9,
-                  "ms_per_launch": node_ms, "launches_per_step": 1, "ms_per_step": node_ms, "traffic": None,
+                  "ms_per_launch": node_ms, "launches_per_step": 1, "ms_per_step": node_ms,
+                  "traffic": (pmc.get("node", {}) or {}).get("traffic_bytes_per_launch"),
                   "note": "executed flops: the condensed n x n systems (n = 36 at an interior node of a tetrahedral grid) "
                           "are 8x less arithmetic than the reference's (nd deg)^2 gradient systems whose count SURVEY 8(d) "
                           "states; both fractions are given.  36 of 64 lanes hold a matrix row: the kernel is bound by "
