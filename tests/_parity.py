@@ -1595,3 +1595,29 @@ def mpsa_large_interaction_region(lib):
         assert np.array_equal(M.indptr, ora[k].indptr) and np.array_equal(M.indices, ora[k].indices), k
         assert rel_max_err(M, ora[k]) < 1e-8, (k, rel_max_err(M, ora[k]))  # sliver cells: conditioning, not a bug
     ctx.close()
+
+
+def mpfa_large_interaction_region(lib, n_ring: int = 70):
+    """MPFA on a Delaunay grid whose hub node is met by more than 64 sub-faces: beyond the register Gauss-Jordan
+    (one lane per row of a 64-lane wavefront), through the LDS elimination; all six matrices against the oracle."""
+    g = hub_tetrahedral_grid(n_ring=n_ring, seed=5)
+    raw = pa.grid_to_raw(g)
+    assert np.bincount(raw["fn_indices"], minlength=g.num_nodes).max() > 64
+    rng = np.random.default_rng(12)
+    nc = g.num_cells
+    k = 1 + rng.random(nc)
+    K = pa.SecondOrderTensor(kxx=k, kyy=2 * k, kzz=0.5 * k, kxy=0.2 * k, kxz=0.05 * k, kyz=0.1 * k)
+    bf = g.get_all_boundary_faces()
+    low = bf[g.face_centers[2, bf] < np.median(g.face_centers[2, bf])]
+    bc = pa.BoundaryCondition(g, low, ["dir"] * low.size)
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(raw)
+    eta = mo.default_eta(raw["name"])
+    ctx.set_params(K.values, pa.bc_flags(bc), None, eta)
+    ctx.discretize()
+    ora = mo.discretize(raw, K.values, pa.bc_to_raw(bc), eta=eta)
+    for i, kname in enumerate(mo.MATRIX_KEYS):
+        M = ctx.matrix(i)
+        assert np.array_equal(M.indptr, ora[kname].indptr) and np.array_equal(M.indices, ora[kname].indices), kname
+        assert rel_max_err(M, ora[kname]) < 1e-8, (kname, rel_max_err(M, ora[kname]))  # sliver cells
+    ctx.close()

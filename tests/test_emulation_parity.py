@@ -290,3 +290,7 @@ def test_amg_robustness_sweep_small(lib):
     out = P.amg_robustness_sweep(lib, scale=0.25)
     for k, (n, its, res) in out.items():
         assert res < 1.05e-10 and its <= 40, (k, n, its, res)
+
+
+def test_interaction_region_with_more_than_64_subfaces(lib):
+    P.mpfa_large_interaction_region(lib)

@@ -359,3 +359,7 @@ def test_partition_arguments_discretize_in_pieces(lib):
     neu = np.setdiff1d(bf, dirf)
     bv[neu[::7]] = 0.01
     P.split_matches_one_piece(lib, g, K, bc, bv, dict(partition_arguments={"num_subproblems": 5}))
+
+
+def test_interaction_region_with_more_than_64_subfaces(lib):
+    P.mpfa_large_interaction_region(lib)
