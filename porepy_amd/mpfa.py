@@ -157,8 +157,9 @@ def estimate_device_bytes(sd) -> int:
 def plan_subproblems(sd, partition_arguments, free_bytes, need=None, what: str = "MPFA") -> int:
     """Number of overlapping sub-grids the discretization is done in (reference: mpfa.py:157-161 with
     _fvutils.parse_partition_arguments, the peak-memory estimate of mpfa.py:1315-1355 and
-    _fvutils.subproblems, _fvutils.py:414-539).  ``num_subproblems`` is taken as given; ``max_memory`` (bytes)
-    bounds the estimated device footprint of one piece; without either the grid is split only when it does
+    _fvutils.subproblems, _fvutils.py:414-539).  ``num_subproblems`` is taken as given; ``max_memory`` bounds the
+    estimated device footprint of one piece in BYTES (the reference compares it with an element-count estimate of
+    its host peak, mpfa.py:1329-1355 -- the key keeps its role, the unit is the device's); without either the grid is split only when it does
     not fit the free HBM of the device."""
     import logging
     import math
