@@ -10,7 +10,8 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib
-from .mpfa import determine_eta
+from .grid import grid_to_raw
+from .mpfa import determine_eta, estimate_device_bytes, partition_cells, plan_subproblems
 from .partial import active_indices
 from .mpsa import Mpsa
 from .mpsa import _KEYS as _MECH_KEYS
@@ -64,6 +65,16 @@ class Biot(Mpsa):
         eta = pd.get("mpsa_eta", None)
         if eta is None:
             eta = determine_eta(sd)
+        self._split.pop(id(sd), None)
+        ent = self._contexts.get(id(sd))
+        if alphas and not (partial or update) and not (
+                ent is not None and ent[0] is sd and ent[1].has_biot_discretization):
+            if self._probe is None:
+                self._probe = _lib.Context(self.device, self._library)
+            nparts = plan_subproblems(sd, pd.get("partition_arguments"), self._probe.free_device_bytes(),
+                                      need=(sd.dim + 1) * estimate_device_bytes(sd), what="Biot")
+            if nparts > 1:
+                return self._biot_in_pieces(sd, data, nparts, float(eta), basis, keys, alphas)
         ctx = self.context(sd)
         is_rob = getattr(bnd, "is_rob", None)
         ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta), is_rob=is_rob,
@@ -115,6 +126,113 @@ class Biot(Mpsa):
             md[name] = {k: ctx.biot_matrix(term, i) for i, k in enumerate(keys)}
         pd["active_cells"] = active_cells
         pd["active_faces"] = active_faces
+
+    def _biot_in_pieces(self, sd, data: dict, nparts: int, eta: float, basis, keys, alphas) -> None:
+        """Memory-bounded discretization (biot.py:246-398 with _fvutils.subproblems): as
+        ``Mpsa._discretize_in_pieces`` for the four MPSA matrices and the two coupling terms with face rows
+        (rows of the faces of a piece's own cells, faces between two pieces averaged); the three terms with cell
+        rows take the rows of a piece's own cells (all nodes of an own cell are complete in the piece)."""
+        import scipy.sparse as sps
+
+        from .distributed import extract_subdomain
+
+        pd = data[PARAMETERS][self.keyword]
+        md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
+        raw = grid_to_raw(sd)
+        nd, nc, nf = sd.dim, sd.num_cells, sd.num_faces
+        Cv = np.asarray(pd["fourth_order_tensor"].values, dtype=float)
+        bnd = pd["bc"]
+        is_dir, is_neu = np.asarray(bnd.is_dir, bool), np.asarray(bnd.is_neu, bool)
+        is_rob = getattr(bnd, "is_rob", None)
+        is_rob = None if is_rob is None or not np.any(is_rob) else np.asarray(is_rob, bool)
+        robw = getattr(bnd, "robin_weight", None)
+        owner = partition_cells(sd, nparts)
+        comp = np.arange(nd)[None, :]
+        # (rows per face?, columns: "c" cells, "C" nd x cells, "F" nd x faces)
+        kinds = {"stress": (True, "C"), "bound_stress": (True, "F"), "bound_displacement_cell": (True, "C"),
+                 "bound_displacement_face": (True, "F"), "scalar_gradient": (True, "c"),
+                 "bound_displacement_pressure": (True, "c"), "displacement_divergence": (False, "C"),
+                 "boundary_displacement_divergence": (False, "F"), "mpsa_consistency": (False, "c")}
+        width = {"c": nc, "C": nd * nc, "F": nd * nf}
+        acc = {(name, None): ([], [], []) for name, _ in _MECH_KEYS}
+        acc.update({(name, k): ([], [], []) for name, _ in _TERMS for k in keys})
+        count = np.zeros(nf, dtype=np.int64)
+        for r in range(nparts):
+            if not np.any(owner == r):
+                continue
+            lp = extract_subdomain(raw, owner, r)
+            ctx = _lib.Context(self.device, self._library)
+            try:
+                ctx.set_grid(lp.raw)
+                art = lp.artificial_boundary
+                ldir, lneu = is_dir[:, lp.face_gid].copy(), is_neu[:, lp.face_gid].copy()
+                ldir[:, art], lneu[:, art] = False, True
+                lrob = None
+                if is_rob is not None:
+                    lrob = is_rob[:, lp.face_gid].copy()
+                    lrob[:, art] = False
+                ctx.mpsa_set_params(np.ascontiguousarray(Cv[:, :, lp.cell_gid]), lp.raw["cell_volumes"], ldir, lneu, eta,
+                                    is_rob=lrob,
+                                    robin_weight=None if (lrob is None or robw is None) else
+                                    np.ascontiguousarray(np.asarray(robw, float)[:, :, lp.face_gid]),
+                                    basis=None if basis is None else np.ascontiguousarray(np.asarray(basis, float)[:, :, lp.face_gid]))
+                ctx.biot_set_alphas([np.ascontiguousarray(a[:, :, lp.cell_gid]) for a in alphas])
+                try:
+                    ctx.biot_discretize(rebuild_topology=True)
+                except _lib.PorefvError as e:
+                    if e.status == 1:
+                        raise ValueError("Error in inversion of local linear systems") from e
+                    if e.status == 2:
+                        raise AssertionError(e.message) from e
+                    raise
+                cfp = lp.raw["cf_indptr"]
+                own_faces = np.unique(lp.raw["cf_indices"][: cfp[lp.n_own]])
+                count[lp.face_gid[own_faces]] += 1
+                frows_l = (nd * own_faces[:, None] + comp).ravel()
+                frows_g = (nd * lp.face_gid[own_faces][:, None] + comp).ravel()
+                cmap = {"c": lp.cell_gid, "C": (nd * lp.cell_gid[:, None] + comp).ravel(),
+                        "F": (nd * lp.face_gid[:, None] + comp).ravel()}
+
+                def take(M, name, key):
+                    face_rows, ck = kinds[name]
+                    if face_rows:
+                        sub = M[frows_l].tocoo()
+                        rows = frows_g[sub.row]
+                    else:
+                        sub = M[: lp.n_own].tocoo()
+                        rows = lp.cell_gid[sub.row]
+                    rr, cc, vv = acc[(name, key)]
+                    rr.append(rows)
+                    cc.append(cmap[ck][sub.col])
+                    vv.append(sub.data)
+
+                for name, which in _MECH_KEYS:
+                    take(ctx.matrix(which), name, None)
+                for name, term in _TERMS:
+                    for i, k in enumerate(keys):
+                        take(ctx.biot_matrix(term, i), name, k)
+            finally:
+                ctx.close()
+        fscale = np.repeat(1.0 / np.maximum(count, 1), nd)
+
+        def merged(name, key):
+            face_rows, ck = kinds[name]
+            rr, cc, vv = (np.concatenate(x) if x else np.zeros(0) for x in acc[(name, key)])
+            nrows = nd * nf if face_rows else nc
+            if face_rows:
+                vv = vv * fscale[rr.astype(np.int64)]
+            M = sps.coo_matrix((vv, (rr, cc)), shape=(nrows, width[ck])).tocsr()
+            M.sum_duplicates()
+            M.sort_indices()
+            return M
+
+        for name, _ in _MECH_KEYS:
+            md[name] = merged(name, None)
+        for name, _ in _TERMS:
+            md[name] = {k: merged(name, k) for k in keys}
+        self._contexts.pop(id(sd), None)
+        pd["active_cells"] = np.arange(nc)
+        pd["active_faces"] = np.arange(nf)
 
     # update_discretization: Mpsa's (modified_cells / modified_faces -> specified_* + update flag)
 

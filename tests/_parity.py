@@ -1621,3 +1621,34 @@ def mpfa_large_interaction_region(lib, n_ring: int = 70):
         assert np.array_equal(M.indptr, ora[kname].indptr) and np.array_equal(M.indices, ora[kname].indices), kname
         assert rel_max_err(M, ora[kname]) < 1e-8, (kname, rel_max_err(M, ora[kname]))  # sliver cells
     ctx.close()
+
+
+def biot_pieces_case(lib, name: str = "biot_tet_2x2x2_mixed", nparts: int = 3):
+    """Biot with partition_arguments: the four MPSA matrices and the five coupling terms per coupling tensor equal
+    the one-piece discretization."""
+    c = BiotCase(name)
+    g = pa.grid_from_raw(c.grid)
+
+    def run(**extra):
+        bc = pa.BoundaryConditionVectorial(g)
+        bc.is_dir, bc.is_neu, bc.is_rob = c.bc["is_dir"].copy(), c.bc["is_neu"].copy(), c.bc["is_rob"].copy()
+        bc.robin_weight = c.bc["robin_weight"]
+        C = type("C", (), {"values": c.stiffness})()
+        maps = {k: type("A", (), {"values": v})() for k, v in c.alphas.items()}
+        data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc,
+                                                    "scalar_vector_mappings": maps, **extra})
+        d = pa.Biot("mechanics", library=lib)
+        d.discretize(g, data)
+        return d, data[pa.DISCRETIZATION_MATRICES]["mechanics"]
+
+    _, one = run()
+    d2, many = run(partition_arguments={"num_subproblems": nparts})
+    assert id(g) not in d2._contexts  # no whole-grid handle
+    for k in MPSA_KEYS:
+        assert many[k].shape == one[k].shape
+        assert abs(many[k] - one[k]).max() <= 1e-11 * max(abs(one[k]).max(), 1e-300), k
+    for k in BIOT_KEYS:
+        for key in c.alphas:
+            A, B = many[k][key], one[k][key]
+            assert A.shape == B.shape, (k, key)
+            assert abs(A - B).max() <= 1e-11 * max(abs(B).max(), 1e-300), (k, key)

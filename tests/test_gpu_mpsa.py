@@ -133,3 +133,8 @@ def test_partition_arguments_discretize_in_pieces(lib, dim):
 
 def test_interaction_region_larger_than_lds(lib):
     P.mpsa_large_interaction_region(lib)
+
+
+@pytest.mark.parametrize("name", ["biot_tri2d_3x3_mixed", "biot_tet_2x2x2_mixed"])
+def test_biot_partition_arguments_discretize_in_pieces(lib, name):
+    P.biot_pieces_case(lib, name)
