@@ -112,11 +112,12 @@ def grid_fingerprint(sd) -> tuple:
 _IGNORED_NOTED: set = set()
 
 
-def note_ignored_parameters(pd: dict, keyword: str) -> None:
-    """Keys the reference's Mpfa reads (mpfa.py:119-167) that have no effect here: say so once per key."""
+def note_ignored_parameters(pd: dict, keyword: str, notes: dict | None = None) -> None:
+    """Keys the reference's Mpfa reads (mpfa.py:119-167; ``notes``: another class's) that have no effect here: say
+    so once per key."""
     import logging
 
-    notes = {
+    notes = notes if notes is not None else {
         "mpfa_inverter": "the local systems are inverted by the device kernel (register Gauss-Jordan); "
                          "the reference's numba / python / cython choice does not apply",
         "reconstruction_eta": "pressure traces are reconstructed at the continuity points of `mpfa_eta`, "

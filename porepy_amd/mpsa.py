@@ -13,7 +13,8 @@ import numpy as np
 
 from . import _lib
 from .grid import grid_to_raw
-from .mpfa import determine_eta, estimate_device_bytes, partition_cells, plan_subproblems, sps_nnz, subface_order
+from .mpfa import (determine_eta, estimate_device_bytes, note_ignored_parameters, partition_cells, plan_subproblems,
+                   sps_nnz, subface_order)
 from .partial import active_indices
 from .params import DISCRETIZATION_MATRICES, PARAMETERS
 
@@ -74,6 +75,14 @@ class Mpsa:
             eta = determine_eta(sd)
         elif np.asarray(eta).size != 1:
             raise NotImplementedError("per-sub-face eta is not covered for MPSA yet")
+        hf_eta = pd.get("reconstruction_eta", None)
+        if hf_eta is not None and float(hf_eta) != float(eta):
+            # mpsa.py:185, 757-761: displacement traces reconstructed at another point than the continuity point;
+            # the device returns the continuity-point values -- refuse rather than return other matrices
+            raise NotImplementedError("reconstruction_eta different from mpsa_eta is not covered")
+        note_ignored_parameters(pd, self.keyword, {
+            "inverter": "the local systems are inverted by the device kernel (register Gauss-Jordan); the reference's "
+                        "numba / python choice does not apply"})
         is_rob = getattr(bnd, "is_rob", None)
         nsub = sps_nnz(sd.face_nodes)
         subface = np.asarray(bnd.is_dir).shape[1] == nsub and nsub != sd.num_faces

@@ -210,3 +210,20 @@ def test_newton_iteration_with_device_resident_jacobian(lib):
             "vector_source": data[pa.DISCRETIZATION_MATRICES]["flow"]["vector_source"]}
     _, _, _, r = ao.flux_system(raw, mats, Kp, a * Kp, p, pa.bc_flags(bc), bv, None, src)
     assert np.linalg.norm(r) < 1e-9 * norms[0]
+
+
+def test_mpsa_reconstruction_eta_is_refused_not_ignored(lib):
+    g = pa.CartGrid([3, 3], [1.0, 1.0])
+    g.compute_geometry()
+    C = pa.FourthOrderTensor(np.ones(g.num_cells), np.ones(g.num_cells))
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    bc.is_dir[:, bf] = True
+    bc.is_neu[:, bf] = False
+    ok = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "mpsa_eta": 0.0,
+                                              "reconstruction_eta": 0.0, "inverter": "python"})
+    pa.Mpsa("mechanics", library=lib).discretize(g, ok)
+    bad = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "mpsa_eta": 0.0,
+                                               "reconstruction_eta": 0.5})
+    with pytest.raises(NotImplementedError, match="reconstruction_eta"):
+        pa.Mpsa("mechanics", library=lib).discretize(g, bad)
