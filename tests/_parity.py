@@ -1620,6 +1620,16 @@ def mpfa_large_interaction_region(lib, n_ring: int = 70):
         M = ctx.matrix(i)
         assert np.array_equal(M.indptr, ora[kname].indptr) and np.array_equal(M.indices, ora[kname].indices), kname
         assert rel_max_err(M, ora[kname]) < 1e-8, (kname, rel_max_err(M, ora[kname]))  # sliver cells
+    # ... and the system of this unstructured grid through assembly and the AMG-preconditioned solve
+    bv = np.zeros(g.num_faces)
+    bv[low] = 1.0 + g.face_centers[0, low]
+    ctx.assemble(bv, None, 0.1 * g.cell_volumes)
+    A = ctx.matrix(pa._lib.MAT_SYSTEM)
+    b = ctx.rhs()
+    x, info = ctx.solve("bicgstab", rtol=1e-12, maxit=5000, raise_on_fail=False, precond="amg")
+    xo = spla.spsolve(A.tocsc(), b)
+    assert info["converged"], info
+    assert np.linalg.norm(x - xo) <= 1e-7 * np.linalg.norm(xo)
     ctx.close()
 
 
