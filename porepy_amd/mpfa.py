@@ -328,7 +328,8 @@ class Mpfa:
                 vcol = (nd * lp.cell_gid[:, None] + np.arange(nd)[None, :]).ravel()
                 for name, which in _KEYS:
                     M = ctx.matrix_rows(which, own_faces).tocoo()
-                    cmap = lp.face_gid if ncols[name] == nf else (vcol if "vector_source" in name else lp.cell_gid)
+                    cmap = (vcol if "vector_source" in name else
+                            lp.face_gid if name in ("bound_flux", "bound_pressure_face") else lp.cell_gid)
                     rr, cc, vv = acc[name]
                     rr.append(lp.face_gid[own_faces][M.row])
                     cc.append(cmap[M.col])

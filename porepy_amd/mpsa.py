@@ -226,7 +226,7 @@ class Mpsa:
                 fcol = (nd * lp.face_gid[:, None] + comp).ravel()
                 for name, which in _KEYS:
                     M = ctx.matrix_rows(which, lrows).tocoo()
-                    cmap = fcol if ncols[name] == nd * nf else ccol
+                    cmap = fcol if name in ("bound_stress", "bound_displacement_face") else ccol
                     rr, cc, vv = acc[name]
                     rr.append(grows[M.row])
                     cc.append(cmap[M.col])

@@ -122,6 +122,22 @@ def test_pieces_on_a_2d_grid_with_mixed_conditions(lib):
     P.split_matches_one_piece(lib, g, K, bc, bv, dict(partition_arguments={"num_subproblems": 3}))
 
 
+def test_pieces_on_a_grid_with_as_many_faces_as_vector_source_columns(lib):
+    """2 x 2 lattice of triangle pairs: 8 cells, 16 faces = nd x cells (found by tools/fuzz_parity.py: the merge must
+    pick the column map by the matrix, not by its width)."""
+    g = pa.StructuredTriangleGrid([2, 2], [1.0, 1.0])
+    g.compute_geometry()
+    assert g.num_faces == 2 * g.num_cells
+    rng = np.random.default_rng(126)
+    nc = g.num_cells
+    K = pa.SecondOrderTensor(kxx=1 + rng.random(nc), kyy=1 + rng.random(nc), kxy=0.2 * rng.random(nc))
+    bf = g.get_all_boundary_faces()
+    bc = pa.BoundaryCondition(g, bf, ["dir", "dir"] + ["neu"] * (bf.size - 2))
+    bv = np.zeros(g.num_faces)
+    bv[bf] = rng.random(bf.size)
+    P.split_matches_one_piece(lib, g, K, bc, bv, dict(partition_arguments={"num_subproblems": 2}))
+
+
 def test_grid_larger_than_free_memory_is_split(lib, monkeypatch):
     g, K, bc, bv = _problem()
     need = pa.mpfa.estimate_device_bytes(g)
