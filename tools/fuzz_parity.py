@@ -3,7 +3,8 @@ grids, random per-face condition types (MPFA: Dirichlet / Neumann / Robin; MPSA:
 TEST INFRASTRUCTURE (imports oracle/):  python tools/fuzz_parity.py [mode] [n_cases] [first_seed]
 modes: core (kernels vs oracles), pieces (partition_arguments vs one piece), subface (conditions per sub-face vs
 oracles), update (update_discretization vs a fresh discretization), solve (Krylov + Jacobi / AMG vs a direct solve),
-biot (coupling terms vs oracle, pieces vs one piece); all = every mode."""
+biot (coupling terms vs oracle, pieces vs one piece); all = every mode.  PFV_FUZZ_DEVICE=1 runs the product library on
+the GPU instead of the host-emulation build."""
 import os
 import sys
 
@@ -334,7 +335,9 @@ def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "core"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    print("suspicious cases:", run_mode(P.emulation_library(), mode, n, seed0))
+    # PFV_FUZZ_DEVICE=1: the gfx950 product library on the GPU instead of the host-emulation build
+    lib = None if os.environ.get("PFV_FUZZ_DEVICE") else P.emulation_library()
+    print("suspicious cases:", run_mode(lib, mode, n, seed0))
 
 
 if __name__ == "__main__":
