@@ -206,7 +206,10 @@ def discretize(
 
         scale = 1.0 / np.abs(G).sum(axis=1)
         try:
-            igrad = np.linalg.inv(scale[:, None] * G) * scale[None, :]
+            Gs = scale[:, None] * G
+            if np.linalg.cond(Gs) > 1e14:  # singular up to rounding: the reference's LAPACK inverse raises on these
+                raise np.linalg.LinAlgError("Singular matrix")
+            igrad = np.linalg.inv(Gs) * scale[None, :]
         except np.linalg.LinAlgError as exc:  # matrix_operations.py:1487-1490
             raise ValueError("Error in inversion of local linear systems") from exc
 
