@@ -4,7 +4,8 @@ pp.Mpfa / pp.Mpsa / pp.Biot (python inverter) against porepy_amd's operator clas
 the kernel sources.  TEST INFRASTRUCTURE.
 
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/repo/oracle/shim:/root/reference/src:/root/repo \\
-      python /root/repo/tools/fuzz_vs_reference.py [n_cases] [first_seed]
+      python /root/repo/tools/fuzz_vs_reference.py [n_cases] [first_seed] [special]
+(`special`: conditions per sub-face, partial discretization, 2-D grids tilted in 3-D, TPFA)
 """
 import os
 import sys
@@ -139,14 +140,162 @@ def case(lib, seed):
     return kind, nc, out
 
 
+def _flow_inputs(g, rng):
+    nd, nc, nf = g.dim, g.num_cells, g.num_faces
+    s = np.exp(0.5 * rng.standard_normal(nc))
+    kw = dict(kxx=s * (1 + rng.random(nc)), kyy=s * (1 + rng.random(nc)), kxy=s * 0.4 * (rng.random(nc) - 0.5))
+    if nd == 3:
+        kw.update(kzz=s * (1 + rng.random(nc)), kxz=s * 0.3 * (rng.random(nc) - 0.5), kyz=s * 0.3 * (rng.random(nc) - 0.5))
+    bf = g.get_all_boundary_faces()
+    types = rng.choice(["dir", "neu", "rob"], size=bf.size, p=[0.5, 0.3, 0.2])
+    types[:2] = "dir"
+    return kw, bf, list(types), 0.2 + 2 * rng.random(nf)
+
+
+def case_special(lib, seed):
+    """Sub-face conditions, partial discretization, a 2-D grid tilted in 3-D, TPFA -- each against the reference."""
+    import scipy.sparse as sps
+    from porepy.numerics.fv import _fvutils
+
+    rng = np.random.default_rng([seed, 7])
+    out = []
+    g, kind = random_ref_grid(rng)
+    g.face_nodes.sort_indices()
+    g.cell_faces.sort_indices()
+    nd, nc, nf = g.dim, g.num_cells, g.num_faces
+    h = pa.grid_from_raw(grid_to_raw(g))
+    kw, bf, types, rw = _flow_inputs(g, rng)
+    # ---- (1) MPFA with conditions per sub-face
+    st = _fvutils.SubcellTopology(g)
+    face_bc = pp.BoundaryCondition(g, bf, types)
+    face_bc.robin_weight = rw.copy()
+    sub = _fvutils.boundary_to_sub_boundary(face_bc, st)
+    flip = np.flatnonzero(sub.is_dir)
+    flip = flip[rng.random(flip.size) < 0.3][1:]
+    sub.is_dir[flip] = False
+    sub.is_neu[flip] = True
+    try:
+        ref = pp.Mpfa("flow")._flux_discretization(g, pp.SecondOrderTensor(**kw), sub, inverter="python", eta=None)
+        hsub = pa.BoundaryCondition(h)
+        hsub.is_dir, hsub.is_neu, hsub.is_rob = sub.is_dir.copy(), sub.is_neu.copy(), sub.is_rob.copy()
+        hsub.is_internal = np.zeros(sub.is_dir.size, bool)
+        hsub.robin_weight = np.asarray(sub.robin_weight, float).copy()
+        hdata = pa.initialize_data({}, "flow", {"second_order_tensor": pa.SecondOrderTensor(**kw), "bc": hsub})
+        pa.Mpfa("flow", library=lib).discretize(h, hdata)
+        o = hdata[pa.DISCRETIZATION_MATRICES]["flow"]
+        out.append(("mpfa, conditions per sub-face", max(rel(o[k], r) for k, r in zip(FLOW, ref))))
+    except (ValueError, np.linalg.LinAlgError) as e:
+        out.append(f"mpfa sub-face: singular input ({type(e).__name__})")
+    # ---- (2) partial discretization
+    spec = {"specified_cells": np.unique(rng.integers(0, nc, size=int(rng.integers(1, 4))))}
+    if rng.random() < 0.4:
+        spec = {"specified_faces": np.unique(rng.integers(0, nf, size=2))}
+    try:
+        rbc = pp.BoundaryCondition(g, bf, types)
+        rbc.robin_weight = rw.copy()
+        rdata = pp.initialize_data({}, "flow", {"second_order_tensor": pp.SecondOrderTensor(**kw), "bc": rbc,
+                                                "mpfa_inverter": "python", **spec})
+        pp.Mpfa("flow").discretize(g, rdata)
+        hbc = pa.BoundaryCondition(h, bf, types)
+        hbc.robin_weight = rw.copy()
+        hdata = pa.initialize_data({}, "flow", {"second_order_tensor": pa.SecondOrderTensor(**kw), "bc": hbc, **spec})
+        pa.Mpfa("flow", library=lib).discretize(h, hdata)
+        r, o = rdata[pp.DISCRETIZATION_MATRICES]["flow"], hdata[pa.DISCRETIZATION_MATRICES]["flow"]
+        af_r, af_o = rdata[pp.PARAMETERS]["flow"]["active_faces"], hdata[pa.PARAMETERS]["flow"]["active_faces"]
+        same = np.array_equal(np.sort(af_r), np.sort(af_o))
+        out.append((f"mpfa, {list(spec)[0]}" + ("" if same else " (ACTIVE FACES DIFFER)"),
+                    max(rel(o[k], r[k]) for k in FLOW) if same else 1.0))
+    except (ValueError, np.linalg.LinAlgError) as e:
+        out.append(f"mpfa partial: singular input ({type(e).__name__})")
+    # ---- (3) a 2-D grid rotated out of the xy-plane, 3-D tensor and vector source
+    if nd == 2:
+        A = rng.standard_normal((3, 3))
+        Q, _ = np.linalg.qr(A)
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] = -Q[:, 0]
+        g3 = g.copy()
+        g3.nodes = Q @ g.nodes
+        g3.compute_geometry()
+        K2 = np.zeros((3, 3, nc))
+        K2[0, 0], K2[1, 1], K2[0, 1], K2[1, 0], K2[2, 2] = kw["kxx"], kw["kyy"], kw["kxy"], kw["kxy"], 1.0
+        K3 = np.einsum("ia,abn,jb->ijn", Q, K2, Q)
+        rK = pp.SecondOrderTensor(kxx=K3[0, 0], kyy=K3[1, 1], kzz=K3[2, 2], kxy=K3[0, 1], kxz=K3[0, 2], kyz=K3[1, 2])
+        hK = pa.SecondOrderTensor(kxx=K3[0, 0], kyy=K3[1, 1], kzz=K3[2, 2], kxy=K3[0, 1], kxz=K3[0, 2], kyz=K3[1, 2])
+        try:
+            rbc = pp.BoundaryCondition(g3, bf, types)
+            rbc.robin_weight = rw.copy()
+            rdata = pp.initialize_data({}, "flow", {"second_order_tensor": rK, "bc": rbc, "mpfa_inverter": "python",
+                                                    "ambient_dimension": 3})
+            pp.Mpfa("flow").discretize(g3, rdata)
+            h3 = pa.grid_from_raw(grid_to_raw(g3))
+            hbc = pa.BoundaryCondition(h3, bf, types)
+            hbc.robin_weight = rw.copy()
+            hdata = pa.initialize_data({}, "flow", {"second_order_tensor": hK, "bc": hbc, "ambient_dimension": 3})
+            pa.Mpfa("flow", library=lib).discretize(h3, hdata)
+            r, o = rdata[pp.DISCRETIZATION_MATRICES]["flow"], hdata[pa.DISCRETIZATION_MATRICES]["flow"]
+            out.append(("mpfa, 2-D grid tilted in 3-D", max(rel(o[k], r[k]) for k in FLOW)))
+        except (ValueError, np.linalg.LinAlgError) as e:
+            out.append(f"mpfa tilted: singular input ({type(e).__name__})")
+    # ---- (4) TPFA
+    rbc = pp.BoundaryCondition(g, bf, types)
+    rbc.robin_weight = rw.copy()
+    rdata = pp.initialize_data({}, "flow", {"second_order_tensor": pp.SecondOrderTensor(**kw), "bc": rbc})
+    pp.Tpfa("flow").discretize(g, rdata)
+    hbc = pa.BoundaryCondition(h, bf, types)
+    hbc.robin_weight = rw.copy()
+    hdata = pa.initialize_data({}, "flow", {"second_order_tensor": pa.SecondOrderTensor(**kw), "bc": hbc})
+    pa.Tpfa("flow", library=lib).discretize(h, hdata)
+    r, o = rdata[pp.DISCRETIZATION_MATRICES]["flow"], hdata[pa.DISCRETIZATION_MATRICES]["flow"]
+    out.append(("tpfa", max(rel(o[k], r[k]) for k in FLOW)))
+    # ---- (5) MPSA with conditions per sub-face, (6) MPSA partial discretization
+    mu, lam = np.exp(0.5 * rng.standard_normal(nc)), np.exp(0.5 * rng.standard_normal(nc))
+    vb = pp.BoundaryConditionVectorial(g)
+    for a in range(nd):
+        t = rng.random(bf.size) < 0.5
+        vb.is_dir[a, bf[t]], vb.is_neu[a, bf[t]] = True, False
+    vb.is_dir[:, bf[:2]], vb.is_neu[:, bf[:2]] = True, False
+    vsub = _fvutils.boundary_to_sub_boundary(vb, st)
+    for a in range(nd):
+        fl = np.flatnonzero(vsub.is_dir[a])
+        fl = fl[rng.random(fl.size) < 0.3][1:]
+        vsub.is_dir[a, fl], vsub.is_neu[a, fl] = False, True
+    try:
+        ref = pp.Mpsa("mechanics")._stress_discretization(g, pp.FourthOrderTensor(mu, lam), vsub, eta=None, inverter="python")
+        hv = pa.BoundaryConditionVectorial(h)
+        hv.is_dir, hv.is_neu, hv.is_rob = vsub.is_dir.copy(), vsub.is_neu.copy(), vsub.is_rob.copy()
+        hv.robin_weight = np.asarray(vsub.robin_weight, float).copy()
+        hv.basis = np.asarray(vsub.basis, float).copy()
+        hv.num_faces = vsub.num_faces
+        hdata = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": pa.FourthOrderTensor(mu, lam), "bc": hv})
+        pa.Mpsa("mechanics", library=lib).discretize(h, hdata)
+        o = hdata[pa.DISCRETIZATION_MATRICES]["mechanics"]
+        out.append(("mpsa, conditions per sub-face", max(rel(o[k], r) for k, r in zip(MECH, ref))))
+    except (ValueError, np.linalg.LinAlgError) as e:
+        out.append(f"mpsa sub-face: singular input ({type(e).__name__})")
+    try:
+        rdata = pp.initialize_data({}, "mechanics", {"fourth_order_tensor": pp.FourthOrderTensor(mu, lam), "bc": vb,
+                                                     "inverter": "python", **spec})
+        pp.Mpsa("mechanics").discretize(g, rdata)
+        hv = pa.BoundaryConditionVectorial(h)
+        hv.is_dir, hv.is_neu = vb.is_dir.copy(), vb.is_neu.copy()
+        hdata = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": pa.FourthOrderTensor(mu, lam), "bc": hv, **spec})
+        pa.Mpsa("mechanics", library=lib).discretize(h, hdata)
+        r, o = rdata[pp.DISCRETIZATION_MATRICES]["mechanics"], hdata[pa.DISCRETIZATION_MATRICES]["mechanics"]
+        out.append((f"mpsa, {list(spec)[0]}", max(rel(o[k], r[k]) for k in MECH)))
+    except (ValueError, np.linalg.LinAlgError) as e:
+        out.append(f"mpsa partial: singular input ({type(e).__name__})")
+    return kind, nc, out
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    fn = case_special if (len(sys.argv) > 3 and sys.argv[3] == "special") else case
     lib = P.emulation_library()
     bad = 0
     for i in range(n):
         try:
-            kind, nc, out = case(lib, seed0 + i)
+            kind, nc, out = fn(lib, seed0 + i)
         except Exception as e:
             bad += 1
             print(f"seed {seed0 + i}: FAILED {type(e).__name__} {str(e)[:200]}", flush=True)
