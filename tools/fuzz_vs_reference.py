@@ -320,6 +320,27 @@ def case_special(lib, seed):
         out.append((f"mpsa, {list(spec)[0]}", max(rel(o[k], r[k]) for k in MECH)))
     except (ValueError, np.linalg.LinAlgError) as e:
         out.append(f"mpsa partial: singular input ({type(e).__name__})")
+    # ---- (7) MPSA with the conditions of every boundary face given in a rotated basis (params/bc.py:222-322)
+    basis = np.tile(np.eye(nd)[:, :, None], (1, 1, nf))
+    for f in bf:
+        Q, _ = np.linalg.qr(rng.standard_normal((nd, nd)))
+        basis[:, :, f] = Q
+    try:
+        rb = pp.BoundaryConditionVectorial(g)
+        rb.is_dir, rb.is_neu = vb.is_dir.copy(), vb.is_neu.copy()
+        rb.basis = basis.copy()
+        rdata = pp.initialize_data({}, "mechanics", {"fourth_order_tensor": pp.FourthOrderTensor(mu, lam), "bc": rb,
+                                                     "inverter": "python"})
+        pp.Mpsa("mechanics").discretize(g, rdata)
+        hv = pa.BoundaryConditionVectorial(h)
+        hv.is_dir, hv.is_neu = vb.is_dir.copy(), vb.is_neu.copy()
+        hv.basis = basis.copy()
+        hdata = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": pa.FourthOrderTensor(mu, lam), "bc": hv})
+        pa.Mpsa("mechanics", library=lib).discretize(h, hdata)
+        r, o = rdata[pp.DISCRETIZATION_MATRICES]["mechanics"], hdata[pa.DISCRETIZATION_MATRICES]["mechanics"]
+        out.append(("mpsa, face-wise basis", max(rel(o[k], r[k]) for k in MECH)))
+    except (ValueError, np.linalg.LinAlgError) as e:
+        out.append(f"mpsa basis: singular input ({type(e).__name__})")
     return kind, nc, out
 
 
