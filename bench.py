@@ -17,8 +17,9 @@ dot products into one all-reduce - this process only serves those two hooks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`` for the
 dominant kernel (CSR SpMV of the solve; live HIP-event timing through pfv_time_kernel) and
-``cpu_baseline`` = the CPU oracle (``oracle/mpfa_oracle.py`` + scipy direct solve) timed on a
-bounded sample of the same workload on this box's host cores.
+``cpu_baseline`` = PorePy's own CPU path (the reference, byte-compiled by ``oracle/make_ref.py`` into
+``oracle/_ref/``) timed on this box's host cores at 196 608 cells of the same workload family; the oracle
+port only where no reference is importable.
 """
 from __future__ import annotations
 
@@ -249,9 +250,46 @@ def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = N
     return lp, K.values, flags, bv, src, 1.0 / 3.0
 
 
-def cpu_baseline(n_side: int):
-    """Oracle (numpy node loop restating the reference's algorithm) + scipy direct solve on a
-    bounded sample: same grid family / tensor / BCs at n_side^3*6 cells, 1 thread."""
+def cpu_baseline_reference(n_side: int, timeout_s: float = 480.0):
+    """PorePy's OWN scipy/numpy CPU path timed on this box's host cores (kind "reference"):
+    ``pp.Mpfa("flow").discretize`` (``mpfa_inverter="python"``: numba is absent) + ``assemble_matrix_rhs`` + the
+    linear solve, run by ``oracle/ref_cpu_baseline.py`` in a subprocess that imports the reference from the live
+    tree (build container) or from ``oracle/_ref/porepy_ref.zip`` (built by ``oracle/make_ref.py``; the GPU box).
+    Same workload family as the timed GPU step at n_side^3*6 cells.  None where no reference is importable."""
+    import subprocess
+
+    import oracle
+
+    env = oracle.ref_env()
+    if env is None:
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_cpu_baseline.py"), str(n_side)],
+                           env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        if not line:
+            return {"error": (r.stderr or "no output")[-400:]}
+        o = json.loads(line[-1][7:])
+    except Exception as e:
+        return {"error": repr(e)}
+    total = o["discretize_s"] + o["assemble_s"] + o["solve_s"]
+    return {
+        "value": o["cells"] / total, "unit": "cells/s", "cores": 1, "kind": "reference",
+        "sample": f"PorePy itself (imported from {'the byte-compiled archive oracle/_ref' if o['porepy_from'].find('.zip') >= 0 else 'the reference tree'}): "
+                  f"{o['cells']} tetrahedra (n_side={n_side}{', BASELINE configs[1] size' if n_side == 32 else ''}) of the timed workload family "
+                  f"(perturbed nodes, anisotropic heterogeneous K): pp.Mpfa.discretize {o['discretize_s']:.1f} s "
+                  f"(mpfa_inverter='python', numba absent) + assemble_matrix_rhs {o['assemble_s']:.2f} s + solve "
+                  f"{o['solve_s']:.1f} s [{o['solver']}; {o['iterations']} iterations, true residual {o['rel_residual']:.1e}]; "
+                  f"peak RSS {o['peak_rss_gb']:.1f} GB; host has {o['host_cores']} cores, the path is effectively "
+                  "single-threaded (scipy csr_matmat + a Python loop of np.linalg.inv)",
+        "seconds": {"discretize": o["discretize_s"], "assemble": o["assemble_s"], "solve": o["solve_s"]},
+        "cells": o["cells"], "check_norm": o["p_norm"], "flux_nnz": o["flux_nnz"],
+    }
+
+
+def cpu_baseline_port(n_side: int):
+    """Fallback where the reference is not importable (kind "port"): the oracle (numpy node loop restating the
+    reference's algorithm) + scipy direct solve on a bounded sample, 1 thread."""
     import scipy.sparse.linalg as spla
 
     import porepy_amd as pa
@@ -275,6 +313,15 @@ def cpu_baseline(n_side: int):
                   f"host has {os.cpu_count()} cores, path is single-threaded",
         "check_norm": float(np.linalg.norm(x)),
     }
+
+
+def cpu_baseline(ref_n_side: int, port_n_side: int):
+    ref = cpu_baseline_reference(ref_n_side)
+    if ref is not None and "error" not in ref:
+        return ref
+    port = cpu_baseline_port(port_n_side)
+    port["reference_unavailable"] = "no reference importable (no /root/reference, no oracle/_ref archive)" if ref is None else ref["error"]
+    return port
 
 
 def source_hash() -> str:
@@ -354,7 +401,9 @@ def main():
                     help="relative tolerance on the TRUE residual; 1e-13 is what 1e-10 field parity needs (SURVEY 8(d))")
     ap.add_argument("--precond", choices=("amg", "jacobi"), default="amg",
                     help="preconditioner of the BiCGStab solve: aggregation-AMG V-cycle (default) or Jacobi")
-    ap.add_argument("--cpu-n-side", type=int, default=16)
+    ap.add_argument("--cpu-n-side", type=int, default=32,
+                    help="lattice side of the reference's CPU run (32 = 196 608 cells, BASELINE configs[1] size: ~2 min)")
+    ap.add_argument("--cpu-port-n-side", type=int, default=16, help="size of the oracle-port fallback")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--no-extra-configs", action="store_true",
@@ -633,7 +682,7 @@ def main():
         except Exception as e:  # diagnostics only
             field = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_n_side)
+        cpu = cpu_baseline(args.cpu_n_side, args.cpu_port_n_side)
     if rank == 0 and world == 1 and not args.force_sharded and args.n_side == 69 and not args.no_extra_configs:
         try:
             opapi = bench_operator_api(pa, lp, Kvals, flags, bv, src, eta, local_rank)

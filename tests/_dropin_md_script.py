@@ -60,7 +60,7 @@ class Model(Geometry, BCs, Permeability, SinglePhaseFlow):
 
 
 class HipSolveModel(pa.HipLinearSolver, Model):
-    hip_library = P.emulation_library()
+    hip_library = P.dropin_library()
 
 
 def run(cls=Model, linear_solver="scipy_sparse", opts=None):
@@ -81,7 +81,7 @@ def run(cls=Model, linear_solver="scipy_sparse", opts=None):
 
 ref = run()
 calls = {}
-HipMpfa = pa.as_porepy_discretization(library=P.emulation_library())
+HipMpfa = pa.as_porepy_discretization(library=P.dropin_library())
 orig = HipMpfa.discretize
 
 
@@ -113,4 +113,5 @@ if "--save" in __import__("sys").argv:
     A = sps.csr_matrix(ref["A"])
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "md_jacobian_box_2fractures.npz")
     np.savez_compressed(path, data=A.data, indices=A.indices, indptr=A.indptr, shape=np.array(A.shape), b=ref["b"], x=ref["x"])
+out["library"] = str(P.dropin_library()._name)
 print("RESULT " + json.dumps(out))

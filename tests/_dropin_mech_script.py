@@ -72,7 +72,7 @@ def run(cls):
 
 ref_mech = run(Mech)
 ref_poro = run(Poro)
-lib = P.emulation_library()
+lib = P.dropin_library()
 calls = {"mpsa": 0, "biot": 0}
 HipMpsa, HipBiot, HipMpfa = pa.as_porepy_mpsa(library=lib), pa.as_porepy_biot(library=lib), pa.as_porepy_discretization(library=lib)
 for cls_, key in ((HipMpsa, "mpsa"), (HipBiot, "biot")):
@@ -95,4 +95,5 @@ out = {
     "poro_x_rel_err": float(np.linalg.norm(our_poro[0] - ref_poro[0]) / np.linalg.norm(ref_poro[0])),
     "poro_A_rel_err": float(abs(our_poro[1] - ref_poro[1]).max() / abs(ref_poro[1]).max()),
 }
+out["library"] = str(P.dropin_library()._name)
 print("RESULT " + json.dumps(out))

@@ -44,7 +44,7 @@ class Model(Geometry, BCs, SinglePhaseFlow):
 
 
 class HipSolveModel(pa.HipLinearSolver, Model):
-    hip_library = P.emulation_library()
+    hip_library = P.dropin_library()
 
 
 def run(cls=Model, linear_solver="scipy_sparse"):
@@ -60,7 +60,7 @@ def run(cls=Model, linear_solver="scipy_sparse"):
 
 ref = run()
 calls = {"n": 0}
-HipMpfa = pa.as_porepy_discretization(library=P.emulation_library())
+HipMpfa = pa.as_porepy_discretization(library=P.dropin_library())
 orig = HipMpfa.discretize
 
 
@@ -83,4 +83,5 @@ out = {
     "p_sum_ref": float(ref[1].sum()),
     "A_rel_err": float(abs(ours[2] - ref[2]).max() / abs(ref[2]).max()),
 }
+out["library"] = str(P.dropin_library()._name)
 print("RESULT " + json.dumps(out))

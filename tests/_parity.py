@@ -34,6 +34,14 @@ def emulation_library():
     return pa._lib.load_library(EMUL_SO)
 
 
+def dropin_library():
+    """Library under the reference's models in tests/_dropin_*_script.py: the host emulation in the build
+    container (no GPU), the PRODUCT library (libporefv_hip.so) when PFV_DROPIN_LIBRARY=product (-m gpu)."""
+    if os.environ.get("PFV_DROPIN_LIBRARY", "emulation") == "product":
+        return pa._lib.product_library()
+    return emulation_library()
+
+
 def flags_of(bc: dict) -> np.ndarray:
     return (bc["is_dir"] * 1 + bc["is_neu"] * 2 + bc["is_rob"] * 4 + bc["is_internal"] * 8).astype(np.uint8)
 

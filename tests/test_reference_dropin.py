@@ -1,5 +1,15 @@
-"""Drop-in check against the reference package itself (build container only; skipped where
-/root/reference is absent): an unmodified PorePy model runs with ``pp.Mpfa`` rebound."""
+"""Drop-in checks against the reference package ITSELF: unmodified PorePy models run with ``pp.Mpfa`` /
+``pp.Mpsa`` / ``pp.Biot`` rebound to the operators of this package.
+
+Two variants of every test:
+* ``emulation`` (``-m "not gpu"``, build container: the live reference tree, no GPU) binds the host-emulation
+  build of the kernel sources;
+* ``product`` (``-m gpu``, the GPU box) binds **libporefv_hip.so**, with the reference imported from the
+  byte-compiled archive ``oracle/_ref/porepy_ref.zip`` that ``oracle/make_ref.py`` builds from the
+  reference tree where it lies (``__graft_entry__.build()`` runs the recipe; the archive is git-ignored
+  and travels with the gpurun snapshot).  This is the call chain ``pp.ad.MpfaAd`` ->
+  ``pp.Mpfa`` rebind (/root/reference/src/porepy/numerics/ad/discretizations.py:195) -> the HIP library.
+Skipped where no reference is importable."""
 import json
 import os
 import subprocess
@@ -7,20 +17,33 @@ import sys
 
 import pytest
 
+import oracle
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = "/root/reference/src"
+
+VARIANTS = [pytest.param("emulation", id="emulation"),
+            pytest.param("product", id="product", marks=pytest.mark.gpu)]
 
 
-@pytest.mark.skipif(not os.path.isdir(REF), reason="reference PorePy not present")
-def test_single_phase_flow_model_with_rebound_mpfa():
-    env = dict(os.environ)
-    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "oracle", "shim"), REF, ROOT])
-    env["PYTHONDONTWRITEBYTECODE"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dropin_script.py")], env=env, cwd="/tmp",
-                       capture_output=True, text=True, timeout=600)
+def run_script(name: str, variant: str, timeout: int = 900, extra_env=None, args=()):
+    env = oracle.ref_env(extra_last=[ROOT], prefer_archive=(variant == "product"))
+    if env is None:
+        pytest.skip("reference PorePy not present (neither /root/reference nor oracle/_ref/porepy_ref.zip)")
+    env["PFV_DROPIN_LIBRARY"] = variant
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", name), *args], env=env, cwd="/tmp",
+                       capture_output=True, text=True, timeout=timeout)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-    assert line, r.stderr[-2000:]
+    assert line, r.stderr[-3000:]
     out = json.loads(line[-1][7:])
+    want = "libporefv_hip.so" if variant == "product" else "libporefv_emul.so"
+    assert os.path.basename(out["library"]) == want, out["library"]
+    return out
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_single_phase_flow_model_with_rebound_mpfa(variant):
+    out = run_script("_dropin_script.py", variant, 600)
     assert out["cells"] == 2500
     assert out["calls_into_device_path"] >= 1
     assert out["p_rel_err"] < 1e-10
@@ -29,37 +52,23 @@ def test_single_phase_flow_model_with_rebound_mpfa():
     assert abs(out["p_sum_ref"] - 8750.0) < 1e-6  # config C1 of the reference
 
 
-@pytest.mark.skipif(not os.path.isdir(REF), reason="reference PorePy not present")
-def test_momentum_balance_and_poromechanics_models_with_rebound_mpsa_biot():
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_momentum_balance_and_poromechanics_models_with_rebound_mpsa_biot(variant):
     """pp.Mpsa, pp.Biot and pp.Mpfa rebound under the reference's own MomentumBalance and
     Poromechanics models: displacement / pressure and the Jacobian reproduce the untouched runs."""
-    env = dict(os.environ)
-    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "oracle", "shim"), REF, ROOT])
-    env["PYTHONDONTWRITEBYTECODE"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dropin_mech_script.py")], env=env, cwd="/tmp",
-                       capture_output=True, text=True, timeout=900)
-    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-    assert line, r.stderr[-2000:]
-    out = json.loads(line[-1][7:])
+    out = run_script("_dropin_mech_script.py", variant)
     assert out["calls"]["mpsa"] >= 1 and out["calls"]["biot"] >= 1
     assert out["mech_dofs"] == 72 and out["poro_dofs"] == 108
     assert out["mech_x_rel_err"] < 1e-10 and out["mech_A_rel_err"] < 1e-10
     assert out["poro_x_rel_err"] < 1e-10 and out["poro_A_rel_err"] < 1e-10
 
 
-@pytest.mark.skipif(not os.path.isdir(REF), reason="reference PorePy not present")
-def test_differentiable_tpfa_transmissibilities_in_the_reference_model():
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_differentiable_tpfa_transmissibilities_in_the_reference_model(variant):
     """The reference's unit-test model of its differentiable TPFA flux (two cells, pressure-dependent
     full-tensor permeability): ``AdTpfaFlux.__transmissibility_matrix`` through its operator tree and
     forward AD against pfv_tpfa_transmissibility_ad chained with the Jacobian of k_c."""
-    env = dict(os.environ)
-    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "oracle", "shim"), REF])
-    env["PYTHONDONTWRITEBYTECODE"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dropin_adtpfa_script.py")], env=env, cwd="/tmp",
-                       capture_output=True, text=True, timeout=600)
-    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-    assert line, r.stderr[-2000:]
-    out = json.loads(line[-1][7:])
+    out = run_script("_dropin_adtpfa_script.py", variant, 600)
     for base in ("tpfa", "mpfa"):
         o = out[base]
         assert o["faces"] == 7 and o["dofs"] == 2 and o["jac_nnz_ref"] > 0
@@ -71,20 +80,13 @@ def test_differentiable_tpfa_transmissibilities_in_the_reference_model():
         assert max(m["flux_rel_err"], m["flux_jac_rel_err"], m["trace_rel_err"], m["trace_jac_rel_err"]) < 1e-12
 
 
-@pytest.mark.skipif(not os.path.isdir(REF), reason="reference PorePy not present")
-def test_mixed_dimensional_model_with_rebound_mpfa_and_hip_solver():
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_mixed_dimensional_model_with_rebound_mpfa_and_hip_solver(variant):
     """The structured stand-in for BASELINE configs[4]: the reference's SinglePhaseFlow on a 3-D box with two
     intersecting fractures (2-D subdomains, 1-D intersection, mortar grids), pp.Mpfa rebound and the coupled
     Jacobian solved by the HIP Krylov solver: all unknowns (matrix, fractures, intersection, mortar fluxes)
     and the Jacobian reproduce the untouched run."""
-    env = dict(os.environ)
-    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "oracle", "shim"), REF, ROOT])
-    env["PYTHONDONTWRITEBYTECODE"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_dropin_md_script.py")], env=env, cwd="/tmp",
-                       capture_output=True, text=True, timeout=900)
-    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-    assert line, r.stderr[-2000:]
-    out = json.loads(line[-1][7:])
+    out = run_script("_dropin_md_script.py", variant)
     assert out["dims"] == [3, 2, 1] and out["subdomains"] == 4 and out["interfaces"] == 4 and out["mortar_cells"] > 0
     assert out["device_calls_by_dim"]["3"] >= 1 and out["device_calls_by_dim"]["2"] >= 2
     assert out["x_rel_err"] < 1e-10 and out["A_rel_err"] < 1e-10

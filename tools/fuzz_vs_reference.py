@@ -1,7 +1,8 @@
 """Randomized differential test against the REFERENCE itself (build container only: the reference package is
 imported through oracle/shim): random grids of the reference's generators, random tensors and condition types;
 pp.Mpfa / pp.Mpsa / pp.Biot (python inverter) against porepy_amd's operator classes on the host-emulation build of
-the kernel sources.  TEST INFRASTRUCTURE.
+the kernel sources, or -- PFV_FUZZ_DEVICE=1, reference from oracle/_ref/porepy_ref.zip -- on libporefv_hip.so on the
+GPU box.  TEST INFRASTRUCTURE.
 
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/repo/oracle/shim:/root/reference/src:/root/repo \\
       python /root/repo/tools/fuzz_vs_reference.py [n_cases] [first_seed] [special]
@@ -360,7 +361,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     fn = case_special if (len(sys.argv) > 3 and sys.argv[3] == "special") else case
-    lib = P.emulation_library()
+    # PFV_FUZZ_DEVICE=1: the gfx950 product library on the GPU (reference from oracle/_ref on the GPU box)
+    lib = None if os.environ.get("PFV_FUZZ_DEVICE") else P.emulation_library()
     bad = 0
     for i in range(n):
         try:
