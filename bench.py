@@ -274,14 +274,16 @@ def cpu_baseline_reference(n_side: int, timeout_s: float = 480.0):
         return {"error": repr(e)}
     total = o["discretize_s"] + o["assemble_s"] + o["solve_s"]
     return {
-        "value": o["cells"] / total, "unit": "cells/s", "cores": 1, "kind": "reference",
+        "value": o["cells"] / total, "unit": "cells/s",
+        "cores": max(1, int(round(o.get("effective_threads", 1.0)))), "kind": "reference",
         "sample": f"PorePy itself (imported from {'the byte-compiled archive oracle/_ref' if o['porepy_from'].find('.zip') >= 0 else 'the reference tree'}): "
                   f"{o['cells']} tetrahedra (n_side={n_side}{', BASELINE configs[1] size' if n_side == 32 else ''}) of the timed workload family "
                   f"(perturbed nodes, anisotropic heterogeneous K): pp.Mpfa.discretize {o['discretize_s']:.1f} s "
                   f"(mpfa_inverter='python', numba absent) + assemble_matrix_rhs {o['assemble_s']:.2f} s + solve "
                   f"{o['solve_s']:.1f} s [{o['solver']}; {o['iterations']} iterations, true residual {o['rel_residual']:.1e}]; "
-                  f"peak RSS {o['peak_rss_gb']:.1f} GB; host has {o['host_cores']} cores, the path is effectively "
-                  "single-threaded (scipy csr_matmat + a Python loop of np.linalg.inv)",
+                  f"peak RSS {o['peak_rss_gb']:.1f} GB; host has {o['host_cores']} cores, process CPU time / wall time = "
+                  f"{o.get('effective_threads', 1.0):.2f} threads busy (scipy csr_matmat and the Python loop of "
+                  "np.linalg.inv are serial; BLAS threads only help the Krylov vectors)",
         "seconds": {"discretize": o["discretize_s"], "assemble": o["assemble_s"], "solve": o["solve_s"]},
         "cells": o["cells"], "check_norm": o["p_norm"], "flux_nnz": o["flux_nnz"],
     }

@@ -54,6 +54,7 @@ def main(n_side: int):
                                               "mpfa_inverter": "python"})
     t_grid = time.perf_counter() - t00
     discr = pp.Mpfa("flow")
+    c0 = time.process_time()
     t0 = time.perf_counter()
     discr.discretize(g, data)
     t1 = time.perf_counter()
@@ -75,6 +76,7 @@ def main(n_side: int):
         p, flag = spla.bicgstab(A, b, rtol=1e-10, atol=0.0, maxiter=20000, M=M, callback=cb)
         solver = f"scipy BiCGStab+Jacobi rtol 1e-10 (flag {flag}); the reference's direct solve does not finish at this size"
     t3 = time.perf_counter()
+    cpu_s = time.process_time() - c0  # all threads of this process: cpu_s / wall = threads effectively busy
     res = float(np.linalg.norm(b - A @ p) / np.linalg.norm(b))
     try:
         import resource
@@ -82,7 +84,7 @@ def main(n_side: int):
     except Exception:
         rss_gb = None
     out = {"cells": int(nc), "n_side": n_side, "grid_s": t_grid, "discretize_s": t1 - t0, "assemble_s": t2 - t1,
-           "solve_s": t3 - t2, "solver": solver, "iterations": its, "rel_residual": res,
+           "solve_s": t3 - t2, "cpu_s": cpu_s, "effective_threads": cpu_s / (t3 - t0), "solver": solver, "iterations": its, "rel_residual": res,
            "flux_nnz": int(data[pp.DISCRETIZATION_MATRICES]["flow"]["flux"].nnz),
            "p_norm": float(np.linalg.norm(p)), "peak_rss_gb": rss_gb,
            "host_cores": os.cpu_count(), "porepy_from": os.path.dirname(pp.__file__),

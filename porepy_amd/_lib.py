@@ -255,6 +255,16 @@ def rccl_unique_id(library=None) -> bytes:
     return buf.raw
 
 
+def rccl_available(library=None) -> bool:
+    """Can this process load librccl through the library?  A purely local probe (ncclGetUniqueId does not
+    communicate): ranks ask it before the collective communicator initialisation."""
+    try:
+        rccl_unique_id(library)
+        return True
+    except PorefvError:
+        return False
+
+
 class RcclComm:
     """Native RCCL transport of a sharded solve (include/porefv.h: pfv_rccl_*): one communicator per rank on
     the device of ``ctx``, plus this rank's halo plan.  Pass it to ``Context.solve_sharded`` in place of the
@@ -264,7 +274,9 @@ class RcclComm:
         self.ctx = ctx
         self.lib = ctx.lib
         self._c = C.c_void_p()
-        st = self.lib.pfv_rccl_comm_create(ctx._h, unique_id, int(rank), int(world), C.byref(self._c))
+        if not isinstance(unique_id, (bytes, bytearray)) or len(unique_id) != 128:
+            raise PorefvError(2, "RCCL unique id must be the 128 bytes of rccl_unique_id()")  # (the library reads 128)
+        st = self.lib.pfv_rccl_comm_create(ctx._h, bytes(unique_id), int(rank), int(world), C.byref(self._c))
         if st != 0:
             raise PorefvError(st, self.lib.pfv_last_error(ctx._h).decode(errors="replace"))
         self.rank, self.world = int(rank), int(world)

@@ -433,21 +433,51 @@ class ShardedMpfa:
         if self.device.type != "cuda" or (dist is not None and dist.get_backend() != "nccl"):
             self._rccl_failed = True
             return None
-        try:
-            ids = [_lib.rccl_unique_id(self.ctx.lib) if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(ids, src=0)
-            comm = _lib.RcclComm(self.ctx, ids[0], rank, world)
-            comm.set_halo_plan({p: v.cpu().numpy() for p, v in self.plan.send.items()},
-                               {q: v.cpu().numpy() for q, v in self.plan.recv.items()})
-            ok = self._rccl_self_test(comm)
-        except _lib.PorefvError:
-            comm, ok = None, False
-        # every rank takes the same decision: the native transport is used only if it passed everywhere
-        if world > 1:
-            flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.device)
+        torch = self.torch
+
+        def all_agree(ok: bool) -> bool:
+            """MIN over the ranks: every rank takes the same branch, and every rank takes part in every collective
+            of this function whatever failed locally (a rank that skipped one would leave its peers hanging)."""
+            if world == 1:
+                return ok
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = bool(int(flag.item()))
+            return bool(int(flag.item()))
+
+        # 1. the unique id: rank 0 ALWAYS broadcasts a payload (ok, id), its own failure included
+        payload = [None]
+        if rank == 0:
+            try:
+                payload = [(True, _lib.rccl_unique_id(self.ctx.lib))]
+            except _lib.PorefvError as e:  # librccl not loadable
+                payload = [(False, str(e))]
+        if world > 1:
+            dist.broadcast_object_list(payload, src=0)
+        have_id = bool(payload[0] and payload[0][0])
+        # 2. can every rank load the library?  Asked BEFORE ncclCommInitRank, which is itself a collective: a
+        #    rank that cannot take part must be known while the others can still stay out of it
+        try:
+            loadable = have_id and bool(_lib.rccl_available(self.ctx.lib))
+        except _lib.PorefvError:
+            loadable = False
+        comm, ok = None, False
+        if all_agree(loadable):
+            try:
+                comm = _lib.RcclComm(self.ctx, payload[0][1], rank, world)
+                comm.set_halo_plan({p: v.cpu().numpy() for p, v in self.plan.send.items()},
+                                   {q: v.cpu().numpy() for q, v in self.plan.recv.items()})
+                ok = True
+            except _lib.PorefvError:
+                ok = False
+            # 3. the self-test (a halo exchange and an all-reduce) only if every communicator exists
+            if all_agree(ok):
+                try:
+                    ok = self._rccl_self_test(comm)
+                except _lib.PorefvError:
+                    ok = False
+                ok = all_agree(ok)
+            else:
+                ok = False
         if ok:
             self._rccl = comm
         else:

@@ -78,13 +78,14 @@ def check_golden_case(lib, name: str):
     assert info["converged"]
     # field: residual in the REFERENCE system, and the field itself where A is well conditioned
     res = np.linalg.norm(c.ref_rhs - c.ref["A"] @ x) / np.linalg.norm(c.ref_rhs)
-    assert res < 1e-11, (name, res)
-    if "hetero" not in name:
+    # (sliver grids: the system matrix is ill conditioned, a 1e-11 difference in its entries shows in the residual)
+    assert res < (1e-8 if "sliver" in name else 1e-11), (name, res)
+    if "hetero" not in name and "sliver" not in name:
         assert np.linalg.norm(x - c.ref_x) <= TOL * np.linalg.norm(c.ref_x), name
     # flux post-processing through the device SpMV
     fl = ctx.spmv(0, x) + ctx.spmv(1, c.bc_values)
     fl_ref = c.ref["flux"] @ c.ref_x + c.ref["bound_flux"] @ c.bc_values
-    assert np.linalg.norm(fl - fl_ref) <= 1e-9 * max(np.linalg.norm(fl_ref), 1e-300)
+    assert np.linalg.norm(fl - fl_ref) <= (1e-6 if "sliver" in name else 1e-9) * max(np.linalg.norm(fl_ref), 1e-300)
     ctx.close()
 
 
@@ -1670,3 +1671,32 @@ def biot_pieces_case(lib, name: str = "biot_tet_2x2x2_mixed", nparts: int = 3):
             A, B = many[k][key], one[k][key]
             assert A.shape == B.shape, (k, key)
             assert abs(A - B).max() <= 1e-11 * max(abs(B).max(), 1e-300), (k, key)
+
+
+def sliver_refinement(lib):
+    """Fixtures made from the reference on Delaunay SLIVER grids (oracle/gen_golden_sliver.py): the plain condensed
+    solves are off by more than 1e-8 there (shown with the refinement switched off), the iterative-refinement path
+    of the node kernels (mpfa_numeric.inc: kRefineKappa) brings every matrix within the 1e-10 gate."""
+    def errs(mode):
+        old = os.environ.get("PFV_NODE_REFINE")
+        os.environ["PFV_NODE_REFINE"] = mode
+        try:
+            c = Case("sliver_delaunay_mixed")
+            ctx = run_case(lib, c)
+            e1 = max(rel_max_err(ctx.matrix(WHICH[k]), c.ref[k]) for k in ALL_KEYS)
+            ctx.close()
+            m = MpsaCase("mpsa_sliver_delaunay")
+            ctx = run_mpsa_case(lib, m)
+            e2 = max(rel_max_err(ctx.matrix(MPSA_WHICH[k]), m.ref[k]) for k in MPSA_KEYS)
+            ctx.close()
+        finally:
+            if old is None:
+                os.environ.pop("PFV_NODE_REFINE", None)
+            else:
+                os.environ["PFV_NODE_REFINE"] = old
+        return e1, e2
+
+    off, on = errs("-1"), errs("0")
+    assert off[0] > 5e-9 and off[1] > 5e-9, off  # the fixtures do exercise the path
+    assert on[0] < TOL and on[1] < TOL, on
+    return off, on

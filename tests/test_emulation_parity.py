@@ -224,6 +224,11 @@ def test_amg_on_assembled_csr_and_symmetric_cg(lib):
     xa, ia = pa.solve_csr(A, b, method="cg", rtol=1e-12, library=lib, precond="amg")
     assert np.linalg.norm(xa - xo) <= 1e-10 * np.linalg.norm(xo)
     assert ia["iterations"] * 2 < ij["iterations"]
+    # the same system in SI-like units (entries ~1e-15): the hierarchy -- incl. the dense inverse of the coarsest
+    # level, whose pivot test is an absolute one on row-scaled systems -- must not depend on the units
+    xs, isc = pa.solve_csr(A * 1e-15, b * 1e-15, method="cg", rtol=1e-12, library=lib, precond="amg")
+    assert isc["iterations"] == ia["iterations"], (isc["iterations"], ia["iterations"])
+    assert np.linalg.norm(xs - xo) <= 1e-10 * np.linalg.norm(xo)
 
 
 @pytest.mark.parametrize("name", ["subface_cart2d_4x3", "subface_tet3d_2x2x2"])
@@ -294,3 +299,7 @@ def test_amg_robustness_sweep_small(lib):
 
 def test_interaction_region_with_more_than_64_subfaces(lib):
     P.mpfa_large_interaction_region(lib)
+
+
+def test_sliver_grids_take_the_iterative_refinement_path(lib):
+    P.sliver_refinement(lib)

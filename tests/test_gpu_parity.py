@@ -363,3 +363,7 @@ def test_partition_arguments_discretize_in_pieces(lib):
 
 def test_interaction_region_with_more_than_64_subfaces(lib):
     P.mpfa_large_interaction_region(lib)
+
+
+def test_sliver_grids_take_the_iterative_refinement_path(lib):
+    P.sliver_refinement(lib)
