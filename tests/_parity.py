@@ -1017,7 +1017,8 @@ def patch_targets(raw: dict, n_random: int = 6, seed: int = 3):
     return cells
 
 
-def grid_patch_parity(lib, raw, Kvals, flags, eta, bv=None, src=None, targets=None, rtol=1e-13, check_solve=True):
+def grid_patch_parity(lib, raw, Kvals, flags, eta, bv=None, src=None, targets=None, rtol=1e-13, check_solve=True,
+                      generic_pattern=False):
     """Rows of ALL SIX device matrices and of A = div flux of one full-size problem (raw grid, permeability
     (3,3,Nc), per-face flags 1 = Dirichlet / 2 = Neumann) against the oracle run on patches cut out of it.
     A face row only involves the interaction regions of the face's nodes, so on a patch = some cells + one
@@ -1044,6 +1045,7 @@ def grid_patch_parity(lib, raw, Kvals, flags, eta, bv=None, src=None, targets=No
               "is_internal": np.zeros(nf, bool), "robin_weight": np.ones(nf)}
     targets = patch_targets(raw) if targets is None else targets
     checked, worst = 0, {}
+    patterns_checked = 0
     ex = lambda idx: (nd * np.asarray(idx)[:, None] + np.arange(nd)[None, :]).ravel()  # noqa: E731
     for c0 in targets:
         inner = cutter.cells_around(c0)
@@ -1069,6 +1071,24 @@ def grid_patch_parity(lib, raw, Kvals, flags, eta, bv=None, src=None, targets=No
             err = rel_max_err(Gl, ora[k][lfaces])
             worst[k] = max(worst.get(k, 0.0), err)
             assert err < TOL, (k, c0, err)
+            # sparsity pattern, bit-exact: the rows of the full-size matrix, renumbered into the patch, carry exactly
+            # the oracle's column indices (the monotone renumbering keeps them sorted); on a generic grid (perturbed
+            # nodes, anisotropic K: the timed one) no stored entry is an exact zero either, i.e. the structural
+            # stencil IS the pattern the reference's sparse products leave (north_star: "sparsity pattern bit-exact")
+            Ol = sps_csr(ora[k][lfaces])
+            Gl.sort_indices()
+            Ol.sort_indices()
+            assert np.array_equal(Gl.indptr, Ol.indptr) and np.array_equal(Gl.indices, Ol.indices), ("pattern", k, c0)
+            patterns_checked += 1
+            if generic_pattern:
+                # (bound_* columns of boundary faces whose condition does not reach the row are structural zeros in
+                # both; only the cell-column matrices are dense in their stencil)
+                # rows of Neumann boundary faces are exact zeros in the cell-column matrices (the flux is the datum)
+                if k in ("flux", "vector_source"):
+                    interior = cutter.sides[gfaces] == 2
+                    rows_of = np.repeat(np.arange(gfaces.size), np.diff(Gl.indptr))
+                    keep = interior[rows_of]
+                    assert np.all(Ol.data[keep] != 0.0) and np.all(Gl.data[keep] != 0.0), ("exact zero in a generic stencil", k, c0)
         if bv is not None:
             Aora, _ = mo.assemble_matrix_rhs(lraw, ora, np.zeros(face_gid.size))
             G = ctx.matrix_rows(pa._lib.MAT_SYSTEM, cell_gid[:n_own]).tocoo()
@@ -1078,7 +1098,8 @@ def grid_patch_parity(lib, raw, Kvals, flags, eta, bv=None, src=None, targets=No
             worst["A"] = max(worst.get("A", 0.0), err)
             assert err < TOL, ("A", c0, err)
         checked += lfaces.size
-    out.update({"rows_checked": checked, "patches": len(targets), "worst_rel_err": worst})
+    out.update({"rows_checked": checked, "patches": len(targets), "worst_rel_err": worst,
+                "patterns_bit_exact": patterns_checked})
     return out
 
 
@@ -1089,7 +1110,8 @@ def bench_grid_patch_parity(lib, n_side: int = 69, n_random: int = 6):
     import bench
 
     lp, Kvals, flags, bv, src, eta = bench.make_slab_problem(n_side, 0, 1)
-    return grid_patch_parity(lib, lp.raw, Kvals, flags, eta, bv, src, patch_targets(lp.raw, n_random))
+    return grid_patch_parity(lib, lp.raw, Kvals, flags, eta, bv, src, patch_targets(lp.raw, n_random),
+                             generic_pattern=True)
 
 
 def config_c2_patch_parity(lib, n_side: int = 32, n_random: int = 6):

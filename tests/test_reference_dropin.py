@@ -91,3 +91,19 @@ def test_mixed_dimensional_model_with_rebound_mpfa_and_hip_solver(variant):
     assert out["device_calls_by_dim"]["3"] >= 1 and out["device_calls_by_dim"]["2"] >= 2
     assert out["x_rel_err"] < 1e-10 and out["A_rel_err"] < 1e-10
     assert out["x_rel_err_hip_solver"] < 1e-10 and out["hip_solver_iterations"] > 0
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_thermo_hydro_mixed_dimensional_model_with_rebound_mpfa(variant):
+    """BASELINE configs[4] as north_star states it -- thermo-hydro coupling on the mixed-dimensional grid: the
+    reference's MassAndEnergyBalance (models/mass_and_energy_balance.py:83) on the 2-fracture stand-in, Darcy AND
+    Fourier flux discretized through the rebound ``pp.Mpfa`` (models/constitutive_laws.py:1078-1088, 2425-2437) on
+    every subdomain of dimension >= 2; two implicit time steps of Newton iterations reproduce the untouched run."""
+    out = run_script("_dropin_thermal_script.py", variant)
+    assert out["variables"] == ["interface_darcy_flux", "interface_enthalpy_flux", "interface_fourier_flux",
+                                "pressure", "temperature"]
+    assert out["dims"] == [3, 2, 1] and out["subdomains"] == 4 and out["interfaces"] == 4
+    c = out["device_calls"]
+    assert c["flow:3"] >= 1 and c["flow:2"] >= 2 and c["fourier_discretization:3"] >= 1 and c["fourier_discretization:2"] >= 2
+    assert out["T_range"][1] - out["T_range"][0] > 1.0 and out["p_range"][1] - out["p_range"][0] > 0.5  # a non-trivial state
+    assert max(out["x_rel_err"], out["T_rel_err"], out["p_rel_err"], out["A_rel_err"]) < 1e-10
