@@ -610,7 +610,10 @@ def main():
     per_step_ms = {e["name"]: e["ms_per_step"] for e in kernels}
 
     # assembly phases (HBM-bound on their CSR output): algorithmic bytes = inputs once + outputs once
-    out_bytes = 8.0 * sum(nnz.values()) + 4.0 * (nnz["flux"] + nnz["bound_flux"] + nnz["vs"]) + 12.0 * nnzA
+    # (the index array of vector_source -- nd x the flux pattern, a pure function of it -- is written on first use
+    # and the timed step never asks for it: its 4 B x nnz are NOT counted, PFV_VS_INDICES_EAGER=1 restores both)
+    vs_index_bytes = 4.0 * nnz["vs"] if os.environ.get("PFV_VS_INDICES_EAGER", "0") not in ("", "0") else 0.0
+    out_bytes = 8.0 * sum(nnz.values()) + 4.0 * (nnz["flux"] + nnz["bound_flux"]) + vs_index_bytes + 12.0 * nnzA
     nfl, nnl = lp.raw["face_centers"].shape[1], lp.raw["nodes"].shape[1]
     in_bytes = 8.0 * (3 * nnl + 3 * nloc + 7 * nfl) + 72.0 * nloc + 5.0 * 4 * nloc + 4.0 * 3 * nfl
     # the interaction-region kernel runs beside the symbolic phase (second stream): the phases overlap, the

@@ -162,6 +162,7 @@ struct pfv_ctx_impl {
   bool have_symbolic = false, have_numeric = false, have_system = false;
   bool rows_complete = false;  // every row of the six MPFA matrices holds a discretization (maybe of older parameters)
   CsrPattern pat_flux, pat_bound, pat_vs, pat_A;  // bound_pressure_* share flux / bound patterns
+  bool vs_indices_pending = false;  // pat_vs.indices not written yet (topology.inc: ensure_vs_indices)
   Buf<double> val[PFV_NUM_MATS];
   bool filled[PFV_NUM_MATS] = {};
   Buf<double> rhs, diag, xsol, face_tmp, vec_in;

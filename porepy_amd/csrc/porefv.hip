@@ -536,6 +536,11 @@ pfv_status pfv_mpfa_discretize_faces(pfv_ctx* h, uint32_t flags, int64_t n_faces
   });
 }
 
+// index arrays that are written on first use (topology.inc: ensure_vs_indices)
+static void materialize_pattern(pfv_ctx* h, int which) {
+  if (which == PFV_MAT_VECTOR_SOURCE || which == PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE) pfv::ensure_vs_indices(*h);
+}
+
 pfv_status pfv_matrix_info(pfv_ctx* h, int which, int64_t* nrows, int64_t* ncols, int64_t* nnz) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
@@ -551,6 +556,7 @@ pfv_status pfv_get_matrix(pfv_ctx* h, int which, int32_t* indptr, int32_t* indic
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
     require(pattern_ready(h, which), "discretize first");
+    if (indices) materialize_pattern(h, which);
     const pfv::CsrPattern& P = h->pattern_of(which);
     auto s = h->stream;
     if (indptr) be_d2h(indptr, P.indptr.p, sizeof(int32_t) * (size_t)(P.nrows + 1), s);
@@ -568,6 +574,7 @@ pfv_status pfv_get_matrix_rows(pfv_ctx* h, int which, int64_t n_rows, const int3
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
     require(pattern_ready(h, which), "discretize first");
     require(n_rows >= 0 && (n_rows == 0 || rows) && out_indptr, "bad row list");
+    if (out_indices || out_data) materialize_pattern(h, which);
     const pfv::CsrPattern& P = h->pattern_of(which);
     for (int64_t i = 0; i < n_rows; ++i) require(rows[i] >= 0 && rows[i] < P.nrows, "row index out of range");
     auto s = h->stream;
@@ -1083,6 +1090,7 @@ pfv_status pfv_spmv(pfv_ctx* h, int which, const double* x, double* y) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS && x && y, "bad argument");
     require((h->have_symbolic || which == PFV_MAT_USER_SYSTEM) && h->filled[which], "matrix values have not been computed");
+    materialize_pattern(h, which);
     const pfv::CsrPattern& P = h->pattern_of(which);
     auto s = h->stream;
     pfv::Buf<double> dx, dy;
@@ -1098,6 +1106,7 @@ pfv_status pfv_spmv_device(pfv_ctx* h, int which, const double* d_x, double* d_y
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS && d_x && d_y, "bad argument");
     require((h->have_symbolic || which == PFV_MAT_USER_SYSTEM) && h->filled[which], "matrix values have not been computed");
+    materialize_pattern(h, which);
     pfv::spmv(*h, h->pattern_of(which), h->val[which], d_x, d_y);
   });
 }
@@ -1106,6 +1115,7 @@ pfv_status pfv_spmv_device_rows(pfv_ctx* h, int which, int64_t nrows, const doub
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS && d_x && d_y, "bad argument");
     require((h->have_symbolic || which == PFV_MAT_USER_SYSTEM) && h->filled[which], "matrix values have not been computed");
+    materialize_pattern(h, which);
     const pfv::CsrPattern& P = h->pattern_of(which);
     require(nrows >= 0 && nrows <= P.nrows, "nrows out of range");
     pfv::CsrPattern V;  // view of the leading rows (shares the index arrays)
