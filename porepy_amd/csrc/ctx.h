@@ -57,6 +57,7 @@ struct CsrPattern {
 struct WinCsr {
   Buf<int64_t> wptr64buf;
   const int64_t* wptr64 = nullptr;  // [nblk + 1] offsets into wcol
+  const int32_t* wlen = nullptr;    // window lengths when the windows sit at a fixed stride (one-pass build); else wptr64 differences
   Buf<int32_t> wcol, cnt;
   Buf<uint16_t> lidx;
   int64_t nblk = 0, nrows = 0, nnz = 0;

@@ -632,7 +632,8 @@ def amg_preconditioner(lib, g, seed=2, hetero_sigma=0.5):
     x3, info3 = d.solve(g, data, source=src, method="bicgstab", rtol=1e-12, precond="amg")
     assert np.array_equal(x2, x3) and info2["iterations"] == info3["iterations"]
     st = d.context(g).stats()
-    assert st["amg_levels"] >= 2 and 1.0 < st["amg_operator_complexity"] < 2.0
+    # (entries of all the cycle's matrices over nnz(A): below 1 when the strength filter thins the finest level too)
+    assert st["amg_levels"] >= 2 and 0.2 < st["amg_operator_complexity"] < 2.0
     assert st["amg_maps_reused"] == 0  # first hierarchy of this pattern
     # new parameter values on the same grid: the patterns stay, the hierarchy keeps its aggregates and
     # redoes the Galerkin products only; the solve is still right and about as fast
