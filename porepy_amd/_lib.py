@@ -280,6 +280,9 @@ class RcclComm:
         if st != 0:
             raise PorefvError(st, self.lib.pfv_last_error(ctx._h).decode(errors="replace"))
         self.rank, self.world = int(rank), int(world)
+        import weakref
+
+        ctx._rccl_refs.append(weakref.ref(self))
 
     def set_halo_plan(self, send: dict, recv: dict):
         """send[p] = local indices of the owned entries peer p needs (in the order it expects them),
@@ -322,6 +325,16 @@ class RcclComm:
             pass
 
 
+def free_device_bytes(device: int = 0, library=None) -> int:
+    """Free HBM on ``device`` right now, through a handle that lives only for the query (no stream or memory pool is
+    kept behind)."""
+    ctx = Context(device, library)
+    try:
+        return ctx.free_device_bytes()
+    finally:
+        ctx.close()
+
+
 class Context:
     """One device handle (one GPU, one HIP stream): grid + parameters + results in HBM."""
 
@@ -338,6 +351,7 @@ class Context:
         self._discretized_m = False  # ... MPSA
         self._discretized_b = False  # ... Biot coupling terms
         self._lazy_refs: list = []   # weak references to LazyCsr proxies of this handle's matrices (lazy.py)
+        self._rccl_refs: list = []   # weak references to the RcclComm objects made on this handle (closed before it)
 
     def _before_overwrite(self):
         """Matrices are about to be recomputed: proxies of the current ones fetch their values first."""
@@ -348,6 +362,12 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            # communicators hold the handle's stream and memory pool: they go first (a communicator destroyed after
+            # its handle would touch freed memory)
+            for ref in getattr(self, "_rccl_refs", []):
+                comm = ref()
+                if comm is not None:
+                    comm.close()
             self.lib.pfv_destroy(self._h)
             self._h = _h()
 

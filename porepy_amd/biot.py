@@ -69,9 +69,7 @@ class Biot(Mpsa):
         ent = self._contexts.get(id(sd))
         if alphas and not (partial or update) and not (
                 ent is not None and ent[0] is sd and ent[1].has_biot_discretization):
-            if self._probe is None:
-                self._probe = _lib.Context(self.device, self._library)
-            nparts = plan_subproblems(sd, pd.get("partition_arguments"), self._probe.free_device_bytes(),
+            nparts = plan_subproblems(sd, pd.get("partition_arguments"), _lib.free_device_bytes(self.device, self._library),
                                       need=(sd.dim + 1) * estimate_device_bytes(sd), what="Biot")
             if nparts > 1:
                 return self._biot_in_pieces(sd, data, nparts, float(eta), basis, keys, alphas)
@@ -231,6 +229,10 @@ class Biot(Mpsa):
         for name, _ in _TERMS:
             md[name] = {k: merged(name, k) for k in keys}
         self._contexts.pop(id(sd), None)
+        # (Mpsa.solve answers with a clear NotImplementedError instead of "discretize first")
+        if not hasattr(self, "_pieces_without_system"):
+            self._pieces_without_system = {}
+        self._pieces_without_system[id(sd)] = sd
         pd["active_cells"] = np.arange(nc)
         pd["active_faces"] = np.arange(nf)
 

@@ -217,7 +217,7 @@ class Mpfa:
         self._plane: dict = {}  # id(sd) -> (2, 3) in-plane basis of a tilted 2-D grid, or None
         self._periodic: dict = {}  # id(sd) -> PeriodicMerge of a grid with periodic faces, or None
         self._split: dict = {}  # id(sd) -> (sd, A) of a grid discretized in pieces (no whole-grid handle exists)
-        self._probe = None  # handle without a grid, for memory queries
+        self._split_ctx = None  # handle the systems of a discretization in pieces are solved on (kept between solves)
 
     # ---- Discretization API ---------------------------------------------------------
     def ndof(self, sd) -> int:
@@ -274,9 +274,7 @@ class Mpfa:
             ctx.set_periodic(merge.native, merge.shift)
 
     def _free_device_bytes(self):
-        if self._probe is None:
-            self._probe = _lib.Context(self.device, self._library)
-        return self._probe.free_device_bytes()
+        return _lib.free_device_bytes(self.device, self._library)
 
     def _discretize_in_pieces(self, sd, data: dict, nparts: int, eta: float) -> None:
         """Memory-bounded discretization (mpfa.py:246-372, _fvutils.py:414-539): the cells are partitioned, every
@@ -354,6 +352,7 @@ class Mpfa:
         A.sort_indices()
         self._split[id(sd)] = (sd, A)
         self._contexts.pop(id(sd), None)
+        self._fingerprints.pop(id(sd), None)
         pd["active_cells"] = np.arange(nc)
         pd["active_faces"] = np.arange(nf)
 
@@ -526,6 +525,7 @@ class Mpfa:
             saved = {k: pd.pop(k, None) for k in ("specified_cells", "specified_faces", "specified_nodes")}
             if remapped:
                 self._contexts.pop(id(sd), None)  # the grid itself changed: upload it again
+                self._fingerprints.pop(id(sd), None)
             try:
                 self.discretize(sd, data)
             finally:
@@ -618,8 +618,10 @@ class Mpfa:
             from .solvers import solve_csr
 
             A, b = self._split_system(sd, data, source)
-            return solve_csr(A, b, method=method, rtol=rtol, maxit=maxit, restart=restart, device=self.device,
-                             library=self._library, precond=precond)
+            if self._split_ctx is None:
+                self._split_ctx = _lib.Context(self.device, self._library)
+            return solve_csr(A, b, method=method, rtol=rtol, maxit=maxit, restart=restart, precond=precond, x0=x0,
+                             context=self._split_ctx)
         ent = self._contexts.get(id(sd))
         if ent is None or ent[0] is not sd:
             raise RuntimeError("discretize(sd, data) must run on this object before solve")

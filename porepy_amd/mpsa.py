@@ -37,7 +37,6 @@ class Mpsa:
         self.bound_displacement_face_matrix_key = "bound_displacement_face"
         self._contexts: dict = {}
         self._split: dict = {}  # id(sd) -> (sd, A) of a grid discretized in pieces (no whole-grid handle exists)
-        self._probe = None
 
     def ndof(self, sd) -> int:
         return sd.dim * sd.num_cells
@@ -89,10 +88,8 @@ class Mpsa:
         self._split.pop(id(sd), None)
         ent = self._contexts.get(id(sd))
         if not (ent is not None and ent[0] is sd and ent[1].has_mpsa_discretization):
-            if self._probe is None:
-                self._probe = _lib.Context(self.device, self._library)
             # the expanded rows of an interaction region are nd x as wide as the MPFA tables, the matrices nd^2 x
-            nparts = plan_subproblems(sd, pd.get("partition_arguments"), self._probe.free_device_bytes(),
+            nparts = plan_subproblems(sd, pd.get("partition_arguments"), _lib.free_device_bytes(self.device, self._library),
                                       need=sd.dim * estimate_device_bytes(sd), what="MPSA")
             if nparts > 1:
                 if not (partial or update or subface):
@@ -326,8 +323,15 @@ class Mpsa:
             from .solvers import solve_csr
 
             A, b = self._split_system(sd, data)
-            return solve_csr(A, b, method=method, rtol=rtol, maxit=maxit, restart=restart, device=self.device,
-                             library=self._library, precond=precond)
+            if getattr(self, "_split_ctx", None) is None:
+                self._split_ctx = _lib.Context(self.device, self._library)  # kept between solves
+            return solve_csr(A, b, method=method, rtol=rtol, maxit=maxit, restart=restart, precond=precond, x0=x0,
+                             context=self._split_ctx)
+        if getattr(self, "_pieces_without_system", {}).get(id(sd)) is sd:
+            raise NotImplementedError(
+                "this grid was discretized in pieces with the Biot coupling terms (partition_arguments / memory "
+                "bound): the mechanics system is not kept on the device -- assemble the coupled system from "
+                "data[DISCRETIZATION_MATRICES] and hand it to porepy_amd.solve_csr")
         ctx = self._assemble(sd, data)
         return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, n=sd.dim * sd.num_cells, restart=restart,
                          precond=precond)
