@@ -569,12 +569,17 @@ def main():
         {"streamed_GBs": (10.0 * nnzA + 4.0 * (nloc + 1) + 8.0 * nloc + 12.0 * nloc * 0.36) / (spmv_ms * 1e-3) / 1e9}))
     if args.precond == "amg" and os.environ.get("PFV_AMG_FP32", "1") != "0":
         sm_ms = ctx.time_kernel(3, reps=50)
-        sm_bytes = 8.0 * nnzA + 4.0 * (nloc + 1) + 4 * 8.0 * nloc  # f32 values + indices, indptr, x, y, b, dinv
+        st_amg = ctx.stats()
+        nnzS = int(st_amg.get("amg_level0_nnz", 0)) or nnzA  # the cycle's finest level: the strength-filtered operator
+        sm_bytes = 8.0 * nnzS + 4.0 * (nloc + 1) + 4 * 8.0 * nloc  # f32 values + indices, indptr, x, y, b, dinv
         kernels.append(hbm_entry(
             "amg_f32_smoothing_product", "k_spmv_win<float, smooth> (finest-level smoothing product of the AMG cycle: "
-            "y = x + w D^-1 (b - A x), f32 matrix values, f64 vectors)", sm_bytes, sm_ms, 4 * its,
-            "achieved = CSR bytes with f32 values (8 B per entry) / time; the kernel streams ~6 B per entry", "smooth",
-            {"streamed_GBs": (6.0 * nnzA + 4.0 * (nloc + 1) + 4 * 8.0 * nloc + 12.0 * nloc * 0.36) / (sm_ms * 1e-3) / 1e9}))
+            "y = x + w D^-1 (b - A_s x), f32 matrix values, f64 vectors)", sm_bytes, sm_ms, 4 * its,
+            f"achieved = CSR bytes with f32 values (8 B per entry) / time; the kernel streams ~6 B per entry.  A_s = the "
+            f"strength-filtered copy of A the cycle works on (theta {st_amg.get('amg_filter_theta', 0.0):.3f}: {nnzS} of "
+            f"{nnzA} entries; the Krylov product keeps A)", "smooth",
+            {"streamed_GBs": (6.0 * nnzS + 4.0 * (nloc + 1) + 4 * 8.0 * nloc + 12.0 * nloc * 0.36) / (sm_ms * 1e-3) / 1e9,
+             "entries": nnzS}))
     nnz = {k: ctx.matrix_info(i)[2] for i, k in enumerate(("flux", "bound_flux", "bpc", "bpf", "vs", "bpvs"))}
     face_ms = ctx.time_kernel(2, reps=3)
     face_bytes = 8.0 * sum(nnz.values())  # every value of the six matrices written once; inputs are intermediate tables
@@ -723,7 +728,8 @@ def main():
                                    "preconditioned BiCGStab to rtol on the TRUE residual",
                        "cells_per_gpu": nc, "krylov": "bicgstab+" + args.precond, "rtol": args.rtol,
                        "amg": ({"levels": st["amg_levels"], "operator_complexity": st["amg_operator_complexity"],
-                                "setup_ms": st["amg_setup_ms"], "coarsest_rows": st["amg_coarsest_rows"]}
+                                "setup_ms": st["amg_setup_ms"], "coarsest_rows": st["amg_coarsest_rows"],
+                                "filter_theta": st.get("amg_filter_theta"), "level0_entries": st.get("amg_level0_nnz")}
                                if args.precond == "amg" else None),
                        "solve_on_renumbered_copy": bool(st.get("solve_renumbered", 0)),
                        "iterations": info["iterations"], "converged": info["converged"],

@@ -112,6 +112,9 @@ typedef struct {
                                      face kernel reads) */
   int64_t amg_maps_reused;        /* 1: the last AMG setup kept the aggregates of the previous one (same pattern,
                                      new values: only the Galerkin products were redone), 0: full setup */
+  int64_t amg_level0_nnz;         /* entries of the matrix the finest level of the cycle smooths with: nnz of the system,
+                                     or of its strength-filtered copy (PFV_AMG_FILTER_PERMIL, scalar systems: default) */
+  double amg_filter_theta;        /* threshold of that filter (0: off) */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);

@@ -376,7 +376,7 @@ struct WaveCtx {
   int lane;      // lane index within the group, 0 .. width-1
   int width;     // lanes per work item: 64 (one wavefront), a power of two below it, or a
                  // multi-wavefront workgroup (block_for)
-  char* red;     // 128 bytes of LDS scratch for cross-wavefront reductions (block_for only)
+  char* red;     // 256 bytes of LDS scratch for cross-wavefront reductions (block_for only)
 #ifdef PFV_EMULATE
   bool lane0() const { return true; }
   void sync() const {}
@@ -422,7 +422,7 @@ struct WaveCtx {
     }
     if (width > 64) {  // combine the wavefronts of the workgroup through LDS
       double* rb = reinterpret_cast<double*>(red);
-      int* rp = reinterpret_cast<int*>(red + 64);
+      int* rp = reinterpret_cast<int*>(red + 128);  // (16 wavefronts of a 1024-thread workgroup: 16 doubles, 16 ints)
       const int nw = width >> 6, wv = lane >> 6;
       __syncthreads();
       if ((lane & 63) == 0) { rb[wv] = b; rp[wv] = p; }
@@ -608,7 +608,7 @@ inline void block_for_global(stream_t s, int64_t n, size_t bytes, Buf<char>& scr
 #else
   const int64_t blocks = n < 256 ? n : 256;
   char* buf = scratch.ensure((size_t)blocks * bytes);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_for_global<T, F>), dim3((unsigned)blocks), dim3(T), 128, s, n, bytes, buf, f);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_for_global<T, F>), dim3((unsigned)blocks), dim3(T), 256, s, n, bytes, buf, f);
   PFV_HIP_CHECK(hipGetLastError());
 #endif
 }
@@ -625,7 +625,7 @@ inline void block_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
     f(w);
   }
 #else
-  const size_t total = lds_bytes + 128;
+  const size_t total = lds_bytes + 256;
   if (total > 160 * 1024) throw Error(5, "work item needs more than 160 KiB of LDS");
   int64_t blocks = n < 256 * 8 ? n : 256 * 8;
   if (total > 48 * 1024) {

@@ -1406,6 +1406,8 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
         h->stats.amg_levels = (int64_t)h->amg->nlev;
         h->stats.amg_coarsest_rows = h->amg->lev[h->amg->nlev - 1]->n;
         h->stats.amg_maps_reused = h->amg->reused ? 1 : 0;
+        h->stats.amg_level0_nnz = h->amg->lev[0]->P->nnz;
+        h->stats.amg_filter_theta = h->amg->filter_level0 ? h->amg->filter_theta : 0.0;
       }
       M.amg = h->amg.get();
       Mp = &M;
