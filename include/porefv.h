@@ -219,6 +219,15 @@ pfv_status pfv_get_matrix(pfv_ctx* h, int which, int32_t* indptr, int32_t* indic
  * -1 / -1 from the host-emulation build.  The host mirror checks its footprint estimate against it before
  * the first discretization of a grid (the reference's peak-memory estimate: mpfa.py:1315-1355). */
 pfv_status pfv_device_memory(pfv_ctx* h, int64_t* free_bytes, int64_t* total_bytes);
+/* Page-locked host memory for the arrays the copy-out calls fill (pfv_get_matrix, pfv_get_rhs, pfv_solve): into such a
+ * buffer the device writes over PCIe directly (~50 GB/s), into pageable memory the runtime stages the copy (23 GB/s
+ * measured) and the freshly allocated pages fault in first (the "eager" operator path moved 23 GB at 6 GB/s that
+ * way).  The host mirror keeps the blocks in a pool and hands them to numpy (porepy_amd/_lib.py: PinnedPool), so that
+ * the matrices of the next time step land in the blocks the previous ones gave back.  Host emulation: malloc / free.
+ * (The reference's matrices are ordinary scipy arrays: fv_elliptic.py:67-112 -- so are these, only their memory
+ * comes from here.) */
+pfv_status pfv_host_alloc(size_t bytes, void** out);
+void pfv_host_free(void* p);
 /* number of unknowns of the system pfv_solve / pfv_get_rhs operate on (0: nothing assembled): the length of
  * the arrays those calls write */
 pfv_status pfv_active_size(pfv_ctx* h, int64_t* n);

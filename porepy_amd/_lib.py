@@ -41,7 +41,7 @@ EXPORTS = [
     "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces", "pfv_solve_sharded", "pfv_tpfa_transmissibility_ad",
     "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
     "pfv_rccl_unique_id", "pfv_rccl_comm_create", "pfv_rccl_set_halo_plan", "pfv_rccl_hooks", "pfv_rccl_stats",
-    "pfv_rccl_last_error", "pfv_rccl_comm_destroy", "pfv_mpfa_ad_flux_system",
+    "pfv_rccl_last_error", "pfv_rccl_comm_destroy", "pfv_mpfa_ad_flux_system", "pfv_host_alloc", "pfv_host_free",
 ]
 
 
@@ -184,6 +184,10 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_rccl_comm_destroy.restype = None
     lib.pfv_device_memory.argtypes = [_h, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.pfv_device_memory.restype = C.c_int
+    lib.pfv_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.pfv_host_alloc.restype = C.c_int
+    lib.pfv_host_free.argtypes = [C.c_void_p]
+    lib.pfv_host_free.restype = None
     lib.pfv_active_size.argtypes = [_h, C.POINTER(C.c_int64)]
     lib.pfv_active_size.restype = C.c_int
     lib.pfv_get_matrix_rows.argtypes = [_h, C.c_int, C.c_int64, _ip, _ip, _ip, _dp]
@@ -323,6 +327,90 @@ class RcclComm:
             self.close()
         except Exception:
             pass
+
+
+class _PinnedBlock:
+    """Owner of one page-locked block: when the last numpy view of it dies the block goes back to its pool."""
+    __slots__ = ("pool", "ptr", "nbytes")
+
+    def __init__(self, pool, ptr, nbytes):
+        self.pool, self.ptr, self.nbytes = pool, ptr, nbytes
+
+    def __del__(self):
+        try:
+            self.pool._give(self.ptr, self.nbytes)
+        except Exception:
+            pass
+
+
+class PinnedPool:
+    """Page-locked host arrays for the results copied out of the device (include/porefv.h: pfv_host_alloc).
+
+    ``empty(n, dtype)`` returns an ordinary numpy array whose memory is a page-locked block; when the array (and
+    whatever scipy matrix holds it) is garbage-collected the block is kept for the next request of the same size --
+    the matrices of a time-stepping loop have the same sizes step after step, so after the first step no memory is
+    pinned, unpinned or page-faulted any more.  Requests below ``min_bytes`` use plain numpy arrays; at most
+    ``PFV_PINNED_POOL_GB`` (default 48) are kept; ``PFV_PINNED_POOL=0`` switches the pool off."""
+
+    min_bytes = 1 << 20
+
+    def __init__(self, lib):
+        import os
+
+        self.lib = lib
+        self.free: dict = {}
+        self.cached = 0
+        self.cap = int(float(os.environ.get("PFV_PINNED_POOL_GB", "48")) * (1 << 30))
+        self.enabled = os.environ.get("PFV_PINNED_POOL", "1") not in ("0", "")
+        self.allocated = 0  # statistics: blocks ever page-locked / requests served from the pool
+        self.reused = 0
+
+    def empty(self, n: int, dtype) -> np.ndarray:
+        dt = np.dtype(dtype)
+        nbytes = int(n) * dt.itemsize
+        if not self.enabled or nbytes < self.min_bytes:
+            return np.empty(int(n), dtype=dt)
+        lst = self.free.get(nbytes)
+        if lst:
+            ptr = lst.pop()
+            self.cached -= nbytes
+            self.reused += 1
+        else:
+            p = C.c_void_p()
+            if self.lib.pfv_host_alloc(nbytes, C.byref(p)) != 0 or not p.value:
+                return np.empty(int(n), dtype=dt)  # no page-locked memory left: pageable
+            ptr = p.value
+            self.allocated += 1
+        buf = (C.c_char * nbytes).from_address(ptr)
+        buf._pfv_owner = _PinnedBlock(self, ptr, nbytes)  # dies with the last view of buf
+        return np.frombuffer(buf, dtype=dt, count=int(n))
+
+    def _give(self, ptr, nbytes):
+        if self.lib is None:
+            return
+        if self.cached + nbytes <= self.cap:
+            self.free.setdefault(nbytes, []).append(ptr)
+            self.cached += nbytes
+        else:
+            self.lib.pfv_host_free(ptr)
+
+    def trim(self):
+        for lst in self.free.values():
+            for ptr in lst:
+                self.lib.pfv_host_free(ptr)
+        self.free.clear()
+        self.cached = 0
+
+
+_POOLS: dict = {}
+
+
+def pinned_pool(lib) -> PinnedPool:
+    """The pool of a library (one per loaded library: the product's blocks are hipHostMalloc'ed, the emulation's malloc'ed)."""
+    key = id(lib)
+    if key not in _POOLS:
+        _POOLS[key] = PinnedPool(lib)
+    return _POOLS[key]
 
 
 def free_device_bytes(device: int = 0, library=None) -> int:
@@ -571,7 +659,7 @@ class Context:
         return m
 
     def active_rhs(self, n=None):
-        b = np.empty(self._active_n(n), dtype=np.float64)
+        b = pinned_pool(self.lib).empty(self._active_n(n), np.float64)
         self._check(self.lib.pfv_get_rhs(self._h, _ptr(b, _dp)))
         return b
 
@@ -629,9 +717,10 @@ class Context:
         import scipy.sparse as sps
 
         nrows, ncols, nnz = self.matrix_info(which)
-        indptr = np.empty(nrows + 1, dtype=np.int32)
-        indices = np.empty(nnz, dtype=np.int32)
-        data = np.empty(nnz, dtype=np.float64)
+        pool = pinned_pool(self.lib)  # page-locked blocks, recycled from the matrices that were collected
+        indptr = pool.empty(nrows + 1, np.int32)
+        indices = pool.empty(nnz, np.int32)
+        data = pool.empty(nnz, np.float64)
         self._check(self.lib.pfv_get_matrix(self._h, which, _ptr(indptr, _ip), _ptr(indices, _ip),
                                             _ptr(data, _dp)))
         if rows is not None:
@@ -719,7 +808,7 @@ class Context:
         ``restart``: GMRES cycle length (0 = 30); ``precond``: "jacobi" or "amg"."""
         code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB, "gmres": SOLVE_GMRES}[method]
         self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1}[precond]))
-        x = np.empty(self._active_n(n), dtype=np.float64)
+        x = pinned_pool(self.lib).empty(self._active_n(n), np.float64)
         x0a = None if x0 is None else _f64(x0)
         if x0a is not None and x0a.shape != x.shape:
             raise ValueError("x0 has the wrong length")

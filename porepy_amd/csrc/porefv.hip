@@ -1072,6 +1072,27 @@ pfv_status pfv_device_memory(pfv_ctx* h, int64_t* free_bytes, int64_t* total_byt
   });
 }
 
+pfv_status pfv_host_alloc(size_t bytes, void** out) {
+  if (!out) return PFV_ERR_ARGUMENT;
+  *out = nullptr;
+  if (bytes == 0) bytes = 8;
+#ifdef PFV_EMULATE
+  *out = std::malloc(bytes);
+  return *out ? PFV_OK : PFV_ERR_HIP;
+#else
+  return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? PFV_OK : PFV_ERR_HIP;
+#endif
+}
+
+void pfv_host_free(void* p) {
+  if (!p) return;
+#ifdef PFV_EMULATE
+  std::free(p);
+#else
+  (void)hipHostFree(p);
+#endif
+}
+
 pfv_status pfv_active_size(pfv_ctx* h, int64_t* n) {
   return guarded(h, [&] {
     require(n != nullptr, "null output");
