@@ -139,7 +139,7 @@ def bench_config_c4(pa, device_index: int, rtol: float, precond: str, steps: int
     # executed flops, 2 n^3 for the Gauss-Jordan inverse + ~40 % for the products that follow it
     n_int = (n - 1) ** 3
     mpsa_flops = n_int * 2.0 * 108 ** 3 * 1.4
-    node_roofline = {"bound": "fp64", "kernel": "mpsa node kernel (512 threads per interaction region; block-cyclic register "
+    node_roofline = {"bound": "mfma", "compute_unit": "FP64 vector FMA (same peak as FP64 MFMA on this part)", "kernel": "mpsa node kernel (512 threads per interaction region; block-cyclic register "
                      "Gauss-Jordan on 256 of them, 8x8 entries per thread, n = 108)", "ms_per_launch": st["node_ms"], "flops_per_launch_estimate": mpsa_flops,
                      "achieved": mpsa_flops / (st["node_ms"] * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                      "frac": mpsa_flops / (st["node_ms"] * 1e-3) / 78.6e12}
@@ -343,7 +343,7 @@ def load_pmc(n_side: int, world: int) -> dict:
     """HBM traffic per launch from the PMC passes of tools/gpu_pmc.sh (FETCH_SIZE and WRITE_SIZE in separate
     runs), if profiles/ holds a file collected with exactly this build on this workload; else {}."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
             pj = json.load(fh)
         if pj.get("n_side") == n_side and world == 1 and pj.get("source_hash") == source_hash():
             return pj["kernels"]
@@ -612,7 +612,9 @@ def main():
     fp64_peak = 78.6e12  # MI355X vector FP64; FP64 MFMA has no higher rate on this part
     nnodes = st["num_nodes"]
     ref_flops = 1.2e6 * nnodes * (st["sum_block_sq"] / max(nnodes, 1) / 36.0 ** 2) ** 1.5  # ~1.2 MFLOP per 36-sub-face node
-    node_entry = {"bound": "fp64", "name": "node_kernel",
+    # bound "mfma" = the compute roofline of the dtype: on MI355X the dense FP64 MFMA peak IS the vector FP64 peak
+    # (78.6 TFLOP/s, MI355X_MICROARCH.md); the kernel issues vector FMAs (see "note")
+    node_entry = {"bound": "mfma", "compute_unit": "FP64 vector FMA (FP64 MFMA has the same peak on this part)", "name": "node_kernel",
                   "kernel": "launch_node_class_reg<64,3,40> (interaction regions: nK, D^-1, condensed system, register "
                             "Gauss-Jordan with partial pivoting, response table A^-1 G)",
                   "achieved": st["node_flops"] / (node_ms * 1e-3) / 1e12, "peak": fp64_peak / 1e12, "unit": "TFLOP/s",
