@@ -317,6 +317,11 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
  * eta as in pfv_mpfa_set_params (scalar). */
 pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const double* cell_volumes,
                                const uint8_t* bc_dir_bits, const uint8_t* bc_neu_bits, double eta);
+/* Continuity points per sub-face for MPSA (`mpsa_eta` given as an array of SubcellTopology.num_subfno_unique values,
+ * numerics/fv/mpsa.py:293-303, 647-652; _fvutils.py:222-277): eta_subface[s] for sub-face s = position of the (face,
+ * node) pair in the face_nodes CSC arrays, used as given also on the boundary.  Call after pfv_mpsa_set_params (which
+ * clears it); NULL removes it. */
+pfv_status pfv_mpsa_set_subface_eta(pfv_ctx* h, const double* eta_subface);
 /* Robin conditions of the vectorial boundary condition (BoundaryConditionVectorial.is_rob,
  * .robin_weight, params/bc.py:222-322; rows of numerics/fv/mpsa.py:1381-1459): bit c of
  * bc_rob_bits[f] = component c of face f is Robin; robin_weight_ddn = weights W[i][a][f], shape

@@ -70,6 +70,17 @@ def sub_half_faces(grid: dict):
     return h_c[order], h_f[order], h_v[order], h_s[order]
 
 
+def subface_ids(grid: dict, faces, node) -> np.ndarray:
+    """Global sub-face id (position of the (face, node) pair in the face_nodes CSC arrays, sorted indices) of the
+    sub-faces `faces` x `node` -- the numbering of SubcellTopology.subfno_unique (_fvutils.py:78-90, 160-172)."""
+    fn_ptr, fn_idx = grid["fn_indptr"], grid["fn_indices"]
+    out = np.empty(len(faces), dtype=np.int64)
+    for i, f in enumerate(faces):
+        seg = fn_idx[fn_ptr[f]:fn_ptr[f + 1]]
+        out[i] = fn_ptr[f] + int(np.flatnonzero(seg == node)[0])
+    return out
+
+
 def discretize(
     grid: dict,
     perm: np.ndarray,
@@ -135,7 +146,10 @@ def discretize(
         # geometry per sub-half-face
         n_h = fnrm[:nd, hf] / nn_face[hf]  # (nd, nh), stored orientation
         nK = np.einsum("ih,ijh->jh", n_h, perm[:nd, :nd, hc])  # n^T K -> (nd, nh)
-        eta_h = np.where(is_bnd_face[hf], 0.0, eta)
+        if np.ndim(eta) == 0:
+            eta_h = np.where(is_bnd_face[hf], 0.0, eta)  # scalar: forced to 0 on the boundary (_fvutils.py:257-268)
+        else:
+            eta_h = np.asarray(eta, float)[subface_ids(grid, hf, v)]  # one value per sub-face, used as given
         fch = fc[:nd, hf]
         if "periodic_native" in grid:
             # merged periodic faces (porepy_amd/periodic.py; reference _fvutils.py:91-137): the side

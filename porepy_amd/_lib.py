@@ -42,6 +42,7 @@ EXPORTS = [
     "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
     "pfv_rccl_unique_id", "pfv_rccl_comm_create", "pfv_rccl_set_halo_plan", "pfv_rccl_hooks", "pfv_rccl_stats",
     "pfv_rccl_last_error", "pfv_rccl_comm_destroy", "pfv_mpfa_ad_flux_system", "pfv_host_alloc", "pfv_host_free",
+    "pfv_mpsa_set_subface_eta",
 ]
 
 
@@ -125,6 +126,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpsa_set_subface_bc.restype = C.c_int
     lib.pfv_mpsa_set_robin.argtypes = [_h, _up, _dp]
     lib.pfv_mpsa_set_robin.restype = C.c_int
+    lib.pfv_mpsa_set_subface_eta.argtypes = [_h, _dp]
+    lib.pfv_mpsa_set_subface_eta.restype = C.c_int
     lib.pfv_reset_stream.argtypes = [_h]
     lib.pfv_reset_stream.restype = C.c_int
     lib.pfv_amg_setup.argtypes = [_h, C.c_int64]
@@ -554,6 +557,14 @@ class Context:
                 raise ValueError("basis must have shape (nd, nd, Nf)")
             if not np.array_equal(B, np.tile(np.eye(self.nd)[:, :, None], (1, 1, self.nf))):
                 self._check(self.lib.pfv_mpsa_set_basis(self._h, _ptr(B, _dp)))
+
+    def mpsa_set_subface_eta(self, eta_subface):
+        """``mpsa_eta`` per sub-face (face_nodes CSC order, sorted indices; mpsa.py:647-652); None removes it.
+        After ``mpsa_set_params``."""
+        es = None if eta_subface is None else _f64(eta_subface)
+        if es is not None and es.shape != (self.nsf,):
+            raise ValueError("size of eta must either be 1 or number of subfaces")
+        self._check(self.lib.pfv_mpsa_set_subface_eta(self._h, _ptr(es, _dp)))
 
     def mpsa_set_subface_bc(self, is_dir_sub, is_neu_sub, is_rob_sub=None, robin_weight_sub=None):
         """Conditions per sub-face (include/porefv.h: pfv_mpsa_set_subface_bc): boolean (nd, Nsf) arrays in the

@@ -65,6 +65,8 @@ class Biot(Mpsa):
         eta = pd.get("mpsa_eta", None)
         if eta is None:
             eta = determine_eta(sd)
+        elif np.asarray(eta).size != 1:
+            raise NotImplementedError("continuity points per sub-face are not covered for the Biot coupling terms")
         self._split.pop(id(sd), None)
         ent = self._contexts.get(id(sd))
         if alphas and not (partial or update) and not (

@@ -178,6 +178,8 @@ struct pfv_ctx_impl {
   Buf<uint8_t> bc_dirbits, bc_neubits, bc_robbits;
   Buf<double> mpsa_robw;             // [nd*nd][Nf] Robin weights
   bool have_mpsa_robin = false;
+  bool have_mpsa_eta_sub = false;  // continuity points per sub-face (pfv_mpsa_set_subface_eta)
+  Buf<double> mpsa_eta_sub;
   Buf<double> mpsa_basis;            // [nd*nd][Nf] boundary basis (BoundaryConditionVectorial.basis)
   bool have_mpsa_basis = false;
   Buf<char> mpsa_scratch;            // global-memory work space of interaction regions too large for the LDS

@@ -718,6 +718,7 @@ pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const do
     upload(h->bc_dirbits, bc_dir_bits, (size_t)h->nf, s);
     upload(h->bc_neubits, bc_neu_bits, (size_t)h->nf, s);
     h->have_mpsa_robin = false;
+    h->have_mpsa_eta_sub = false;
     h->have_mpsa_basis = false;
     h->mpsa_subface_bc = false;
     h->mpsa_eta = eta;
@@ -743,6 +744,19 @@ pfv_status pfv_mpsa_set_robin(pfv_ctx* h, const uint8_t* bc_rob_bits, const doub
       upload(h->mpsa_robw, eye.data(), n2 * nf, s);
     }
     h->have_mpsa_robin = true;
+    h->have_mpsa_numeric = false;
+    h->have_mech_system = false;
+  });
+}
+
+pfv_status pfv_mpsa_set_subface_eta(pfv_ctx* h, const double* eta_subface) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_mpsa_params, "pfv_mpsa_set_params first");
+    h->have_mpsa_eta_sub = false;
+    if (eta_subface) {
+      upload(h->mpsa_eta_sub, eta_subface, (size_t)h->nsf, h->stream);
+      h->have_mpsa_eta_sub = true;
+    }
     h->have_mpsa_numeric = false;
     h->have_mech_system = false;
   });

@@ -408,7 +408,12 @@ class Mpfa:
         if eta is None:
             eta = determine_eta(sd)
         elif np.asarray(eta).size != 1:
-            eta_sub = np.asarray(eta, dtype=float)
+            # (the values follow the storage order of the caller's face_nodes, the device numbers sub-faces by the
+            # sorted CSC arrays: _fvutils.py:78-90, 222-277)
+            eta_sub = np.asarray(eta, dtype=float).ravel()
+            if eta_sub.size != sps_nnz(sd.face_nodes):
+                raise ValueError("size of eta must either be 1 or number of subfaces")
+            eta_sub = eta_sub[subface_order(sd.face_nodes)]
             eta = 0.0
         note_ignored_parameters(pd, self.keyword)
         self._split.pop(id(sd), None)

@@ -69,13 +69,21 @@ class Mpsa:
         spec = [pd.get(k) for k in ("specified_cells", "specified_faces", "specified_nodes")]
         partial = any(v is not None for v in spec)
         update = bool(pd.get("update_discretization", False))
+        nsub = sps_nnz(sd.face_nodes)
         eta = pd.get("mpsa_eta", None)
+        eta_sub = None
         if eta is None:
             eta = determine_eta(sd)
         elif np.asarray(eta).size != 1:
-            raise NotImplementedError("per-sub-face eta is not covered for MPSA yet")
+            # one continuity point per sub-face, used as given also on the boundary (mpsa.py:293-303, 647-652;
+            # _fvutils.py:222-277); the values follow the storage order of the caller's face_nodes
+            eta_sub = np.asarray(eta, dtype=float).ravel()
+            if eta_sub.size != nsub:
+                raise ValueError("size of eta must either be 1 or number of subfaces")
+            eta_sub = eta_sub[subface_order(sd.face_nodes)]
+            eta = 0.0
         hf_eta = pd.get("reconstruction_eta", None)
-        if hf_eta is not None and float(hf_eta) != float(eta):
+        if hf_eta is not None and (eta_sub is not None or float(hf_eta) != float(eta)):
             # mpsa.py:185, 757-761: displacement traces reconstructed at another point than the continuity point;
             # the device returns the continuity-point values -- refuse rather than return other matrices
             raise NotImplementedError("reconstruction_eta different from mpsa_eta is not covered")
@@ -83,7 +91,6 @@ class Mpsa:
             "inverter": "the local systems are inverted by the device kernel (register Gauss-Jordan); the reference's "
                         "numba / python choice does not apply"})
         is_rob = getattr(bnd, "is_rob", None)
-        nsub = sps_nnz(sd.face_nodes)
         subface = np.asarray(bnd.is_dir).shape[1] == nsub and nsub != sd.num_faces
         self._split.pop(id(sd), None)
         ent = self._contexts.get(id(sd))
@@ -92,7 +99,7 @@ class Mpsa:
             nparts = plan_subproblems(sd, pd.get("partition_arguments"), _lib.free_device_bytes(self.device, self._library),
                                       need=sd.dim * estimate_device_bytes(sd), what="MPSA")
             if nparts > 1:
-                if not (partial or update or subface):
+                if not (partial or update or subface or eta_sub is not None):
                     return self._discretize_in_pieces(sd, data, nparts, float(eta), basis)
                 import logging
 
@@ -121,6 +128,7 @@ class Mpsa:
                                 is_rob=is_rob,
                                 robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None,
                                 basis=basis)
+        ctx.mpsa_set_subface_eta(eta_sub)  # (None: the scalar eta of mpsa_set_params)
         rows = None
         try:
             if partial:

@@ -73,6 +73,7 @@ class MpsaCase:
         self.source = z["source"]
         eta = float(z["eta"])
         self.eta = None if np.isnan(eta) else eta
+        self.eta_sub = z["eta_sub"] if "eta_sub" in z.files else None  # continuity points per sub-face (sorted CSC order)
         self.ref = {}
         for k in MPSA_KEYS + ("A",):
             if f"ref_{k}_indptr" in z.files:
@@ -99,6 +100,7 @@ class Case:
         self.source = z["source"]
         eta = float(z["eta"])
         self.eta = None if np.isnan(eta) else eta
+        self.eta_sub = z["eta_sub"] if "eta_sub" in z.files else None  # continuity points per sub-face (sorted CSC order)
         self.vector_source_values = z["vector_source_values"] if "vector_source_values" in z.files else None
         self.ref = {}
         for k in ALL_KEYS + ("A",):

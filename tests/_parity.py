@@ -60,7 +60,7 @@ def run_case(lib, c: Case):
     ctx = pa.Context(0, lib)
     ctx.set_grid(c.grid)
     eta = c.eta if c.eta is not None else mo.default_eta(c.grid["name"])
-    ctx.set_params(c.perm, flags_of(c.bc), c.bc["robin_weight"], eta)
+    ctx.set_params(c.perm, flags_of(c.bc), c.bc["robin_weight"], eta, getattr(c, "eta_sub", None))
     ctx.discretize()
     return ctx
 
@@ -69,7 +69,7 @@ def check_golden_case(lib, name: str):
     c = Case(name)
     TOL = tol_for(name)  # noqa: N806
     ctx = run_case(lib, c)
-    ora = mo.discretize(c.grid, c.perm, c.bc, eta=c.eta)
+    ora = mo.discretize(c.grid, c.perm, c.bc, eta=c.eta_sub if c.eta_sub is not None else c.eta)
     for k in ALL_KEYS:
         M = ctx.matrix(WHICH[k])
         assert M.indices.dtype == np.int32 and M.has_sorted_indices
@@ -371,6 +371,8 @@ def run_mpsa_case(lib, c: MpsaCase):
     eta = c.eta if c.eta is not None else mo.default_eta(c.grid["name"])
     ctx.mpsa_set_params(c.stiffness, c.grid["cell_volumes"], c.bc["is_dir"], c.bc["is_neu"], eta,
                         is_rob=c.bc.get("is_rob"), robin_weight=c.bc.get("robin_weight"), basis=c.bc.get("basis"))
+    if getattr(c, "eta_sub", None) is not None:
+        ctx.mpsa_set_subface_eta(c.eta_sub)
     ctx.mpsa_discretize()
     return ctx
 
@@ -379,7 +381,7 @@ def check_mpsa_golden_case(lib, name: str):
     c = MpsaCase(name)
     TOL = tol_for(name)  # noqa: N806
     ctx = run_mpsa_case(lib, c)
-    ora = so.discretize(c.grid, c.stiffness, c.bc, eta=c.eta)
+    ora = so.discretize(c.grid, c.stiffness, c.bc, eta=c.eta_sub if c.eta_sub is not None else c.eta)
     for k in MPSA_KEYS:
         M = ctx.matrix(MPSA_WHICH[k])
         assert M.indices.dtype == np.int32 and M.has_sorted_indices
