@@ -322,6 +322,12 @@ pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const do
  * node) pair in the face_nodes CSC arrays, used as given also on the boundary.  Call after pfv_mpsa_set_params (which
  * clears it); NULL removes it. */
 pfv_status pfv_mpsa_set_subface_eta(pfv_ctx* h, const double* eta_subface);
+/* `reconstruction_eta` (numerics/fv/mpsa.py:185, 757-761, _reconstruct_displacement :1187-1266): the displacement
+ * traces (bound_displacement_cell / bound_displacement_face) are reconstructed at x_f + hf_eta (x_v - x_f) from the
+ * sub-cell gradients, averaged over the two sides of the sub-face, instead of at the continuity points (a scalar: 0
+ * on boundary faces, as the reference's distance routine does).  on = 0 switches back.  After pfv_mpsa_set_params
+ * (which clears it).  Not combined with the Biot coupling terms or conditions per sub-face (PFV_ERR_UNSUPPORTED). */
+pfv_status pfv_mpsa_set_reconstruction_eta(pfv_ctx* h, int on, double hf_eta);
 /* Robin conditions of the vectorial boundary condition (BoundaryConditionVectorial.is_rob,
  * .robin_weight, params/bc.py:222-322; rows of numerics/fv/mpsa.py:1381-1459): bit c of
  * bc_rob_bits[f] = component c of face f is Robin; robin_weight_ddn = weights W[i][a][f], shape

@@ -4,7 +4,7 @@ REFERENCE PorePy.   TEST INFRASTRUCTURE; build container only:
       PYTHONPATH=/root/repo/oracle/shim:/root/reference/src:/root/repo python /root/repo/oracle/gen_golden_etasub.py
 ``mpfa_eta`` / ``mpsa_eta`` given as arrays of SubcellTopology.num_subfno_unique values (numerics/fv/_fvutils.py:222-277,
 mpfa.py:599-609, mpsa.py:293-303, 647-652): every sub-face its own continuity point, used as given also on the
-boundary.  The reference's own tests never exercise the array form."""
+boundary.  The reference's own tests never exercise the array form.  Also: ``reconstruction_eta`` (mpsa_hfeta_*)."""
 from __future__ import annotations
 
 import os
@@ -48,6 +48,11 @@ def main():
         eta_sub = 0.05 + 0.35 * rng.random(g.face_nodes.nnz)
         gm.save_case(name, g, C, bc, bv.ravel("F"), rng.random(nd * nc) * np.repeat(g.cell_volumes, nd), eta=eta_sub,
                      extra={"eta": np.array(np.nan), "eta_sub": eta_sub})
+        # --- the same problem with ``reconstruction_eta`` different from a scalar ``mpsa_eta`` (mpsa.py:185, 757-761):
+        # displacement traces reconstructed at x_f + 0.1 (x_v - x_f)
+        gm.save_case(name.replace("etasub", "hfeta"), g, C, bc, bv.ravel("F"),
+                     rng.random(nd * nc) * np.repeat(g.cell_volumes, nd), eta=1.0 / 3.0,
+                     extra={"hf_eta": np.array(0.1)}, more_params={"reconstruction_eta": 0.1})
 
 
 if __name__ == "__main__":

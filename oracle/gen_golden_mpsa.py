@@ -28,11 +28,13 @@ from oracle.ref_bridge import grid_to_raw  # noqa: E402
 KEYS = ("stress", "bound_stress", "bound_displacement_cell", "bound_displacement_face")
 
 
-def save_case(name, g, C, bc, bc_values, source, eta=None, extra=None, keys=KEYS):
+def save_case(name, g, C, bc, bc_values, source, eta=None, extra=None, keys=KEYS, more_params=None):
     params = {"fourth_order_tensor": C, "bc": bc, "inverter": "python", "bc_values": bc_values,
               "source": source}
     if eta is not None:
         params["mpsa_eta"] = eta
+    if more_params:
+        params.update(more_params)
     data = pp.initialize_data({}, "mechanics", params)
     discr = pp.Mpsa("mechanics")
     discr.discretize(g, data)

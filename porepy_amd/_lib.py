@@ -42,7 +42,7 @@ EXPORTS = [
     "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
     "pfv_rccl_unique_id", "pfv_rccl_comm_create", "pfv_rccl_set_halo_plan", "pfv_rccl_hooks", "pfv_rccl_stats",
     "pfv_rccl_last_error", "pfv_rccl_comm_destroy", "pfv_mpfa_ad_flux_system", "pfv_host_alloc", "pfv_host_free",
-    "pfv_mpsa_set_subface_eta",
+    "pfv_mpsa_set_subface_eta", "pfv_mpsa_set_reconstruction_eta",
 ]
 
 
@@ -128,6 +128,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpsa_set_robin.restype = C.c_int
     lib.pfv_mpsa_set_subface_eta.argtypes = [_h, _dp]
     lib.pfv_mpsa_set_subface_eta.restype = C.c_int
+    lib.pfv_mpsa_set_reconstruction_eta.argtypes = [_h, C.c_int, C.c_double]
+    lib.pfv_mpsa_set_reconstruction_eta.restype = C.c_int
     lib.pfv_reset_stream.argtypes = [_h]
     lib.pfv_reset_stream.restype = C.c_int
     lib.pfv_amg_setup.argtypes = [_h, C.c_int64]
@@ -565,6 +567,12 @@ class Context:
         if es is not None and es.shape != (self.nsf,):
             raise ValueError("size of eta must either be 1 or number of subfaces")
         self._check(self.lib.pfv_mpsa_set_subface_eta(self._h, _ptr(es, _dp)))
+
+    def mpsa_set_reconstruction_eta(self, hf_eta):
+        """``reconstruction_eta`` (mpsa.py:185, 757-761): where the displacement traces are reconstructed; None = at
+        the continuity points.  After ``mpsa_set_params``."""
+        self._check(self.lib.pfv_mpsa_set_reconstruction_eta(self._h, 0 if hf_eta is None else 1,
+                                                             0.0 if hf_eta is None else float(hf_eta)))
 
     def mpsa_set_subface_bc(self, is_dir_sub, is_neu_sub, is_rob_sub=None, robin_weight_sub=None):
         """Conditions per sub-face (include/porefv.h: pfv_mpsa_set_subface_bc): boolean (nd, Nsf) arrays in the

@@ -67,6 +67,9 @@ class Biot(Mpsa):
             eta = determine_eta(sd)
         elif np.asarray(eta).size != 1:
             raise NotImplementedError("continuity points per sub-face are not covered for the Biot coupling terms")
+        hf_eta = pd.get("reconstruction_eta", None)
+        if hf_eta is not None and (np.asarray(hf_eta).size != 1 or float(hf_eta) != float(eta)):
+            raise NotImplementedError("reconstruction_eta different from mpsa_eta is not covered for the Biot coupling terms")
         self._split.pop(id(sd), None)
         ent = self._contexts.get(id(sd))
         if alphas and not (partial or update) and not (

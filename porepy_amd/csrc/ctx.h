@@ -179,6 +179,9 @@ struct pfv_ctx_impl {
   Buf<double> mpsa_robw;             // [nd*nd][Nf] Robin weights
   bool have_mpsa_robin = false;
   bool have_mpsa_eta_sub = false;  // continuity points per sub-face (pfv_mpsa_set_subface_eta)
+  bool mpsa_hf_on = false;         // reconstruction_eta given (pfv_mpsa_set_reconstruction_eta)
+  double mpsa_hf_eta = 0.0;
+  Buf<double> Et2, Etb2;           // traces reconstructed at the hf_eta points (layout of Et / Etb)
   Buf<double> mpsa_eta_sub;
   Buf<double> mpsa_basis;            // [nd*nd][Nf] boundary basis (BoundaryConditionVectorial.basis)
   bool have_mpsa_basis = false;

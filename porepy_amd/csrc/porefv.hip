@@ -719,6 +719,7 @@ pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const do
     upload(h->bc_neubits, bc_neu_bits, (size_t)h->nf, s);
     h->have_mpsa_robin = false;
     h->have_mpsa_eta_sub = false;
+    h->mpsa_hf_on = false;
     h->have_mpsa_basis = false;
     h->mpsa_subface_bc = false;
     h->mpsa_eta = eta;
@@ -757,6 +758,17 @@ pfv_status pfv_mpsa_set_subface_eta(pfv_ctx* h, const double* eta_subface) {
       upload(h->mpsa_eta_sub, eta_subface, (size_t)h->nsf, h->stream);
       h->have_mpsa_eta_sub = true;
     }
+    h->have_mpsa_numeric = false;
+    h->have_mech_system = false;
+  });
+}
+
+pfv_status pfv_mpsa_set_reconstruction_eta(pfv_ctx* h, int on, double hf_eta) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_mpsa_params, "pfv_mpsa_set_params first");
+    require(!on || (hf_eta >= 0.0 && hf_eta < 1.0), "reconstruction_eta must lie in [0, 1)");
+    h->mpsa_hf_on = on != 0;
+    h->mpsa_hf_eta = hf_eta;
     h->have_mpsa_numeric = false;
     h->have_mech_system = false;
   });

@@ -83,10 +83,10 @@ class Mpsa:
             eta_sub = eta_sub[subface_order(sd.face_nodes)]
             eta = 0.0
         hf_eta = pd.get("reconstruction_eta", None)
-        if hf_eta is not None and (eta_sub is not None or float(hf_eta) != float(eta)):
-            # mpsa.py:185, 757-761: displacement traces reconstructed at another point than the continuity point;
-            # the device returns the continuity-point values -- refuse rather than return other matrices
-            raise NotImplementedError("reconstruction_eta different from mpsa_eta is not covered")
+        if hf_eta is not None and np.asarray(hf_eta).size != 1:
+            raise NotImplementedError("reconstruction_eta per sub-face is not covered")
+        if hf_eta is not None and eta_sub is None and float(hf_eta) == float(eta):
+            hf_eta = None  # the continuity points themselves
         note_ignored_parameters(pd, self.keyword, {
             "inverter": "the local systems are inverted by the device kernel (register Gauss-Jordan); the reference's "
                         "numba / python choice does not apply"})
@@ -99,7 +99,7 @@ class Mpsa:
             nparts = plan_subproblems(sd, pd.get("partition_arguments"), _lib.free_device_bytes(self.device, self._library),
                                       need=sd.dim * estimate_device_bytes(sd), what="MPSA")
             if nparts > 1:
-                if not (partial or update or subface or eta_sub is not None):
+                if not (partial or update or subface or eta_sub is not None or hf_eta is not None):
                     return self._discretize_in_pieces(sd, data, nparts, float(eta), basis)
                 import logging
 
@@ -129,6 +129,10 @@ class Mpsa:
                                 robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None,
                                 basis=basis)
         ctx.mpsa_set_subface_eta(eta_sub)  # (None: the scalar eta of mpsa_set_params)
+        if hf_eta is not None and (subface or partial or update):
+            raise NotImplementedError("reconstruction_eta with conditions per sub-face or partial updates is not covered")
+        # displacement traces reconstructed at x_f + hf_eta (x_v - x_f) (mpsa.py:185, 757-761, 1187-1266)
+        ctx.mpsa_set_reconstruction_eta(None if hf_eta is None else float(hf_eta))
         rows = None
         try:
             if partial:

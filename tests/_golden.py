@@ -74,6 +74,7 @@ class MpsaCase:
         eta = float(z["eta"])
         self.eta = None if np.isnan(eta) else eta
         self.eta_sub = z["eta_sub"] if "eta_sub" in z.files else None  # continuity points per sub-face (sorted CSC order)
+        self.hf_eta = float(z["hf_eta"]) if "hf_eta" in z.files else None  # reconstruction_eta
         self.ref = {}
         for k in MPSA_KEYS + ("A",):
             if f"ref_{k}_indptr" in z.files:

@@ -373,6 +373,8 @@ def run_mpsa_case(lib, c: MpsaCase):
                         is_rob=c.bc.get("is_rob"), robin_weight=c.bc.get("robin_weight"), basis=c.bc.get("basis"))
     if getattr(c, "eta_sub", None) is not None:
         ctx.mpsa_set_subface_eta(c.eta_sub)
+    if getattr(c, "hf_eta", None) is not None:
+        ctx.mpsa_set_reconstruction_eta(c.hf_eta)
     ctx.mpsa_discretize()
     return ctx
 
@@ -381,7 +383,7 @@ def check_mpsa_golden_case(lib, name: str):
     c = MpsaCase(name)
     TOL = tol_for(name)  # noqa: N806
     ctx = run_mpsa_case(lib, c)
-    ora = so.discretize(c.grid, c.stiffness, c.bc, eta=c.eta_sub if c.eta_sub is not None else c.eta)
+    ora = so.discretize(c.grid, c.stiffness, c.bc, eta=c.eta_sub if c.eta_sub is not None else c.eta, hf_eta=c.hf_eta)
     for k in MPSA_KEYS:
         M = ctx.matrix(MPSA_WHICH[k])
         assert M.indices.dtype == np.int32 and M.has_sorted_indices

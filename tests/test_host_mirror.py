@@ -228,18 +228,34 @@ def test_newton_iteration_with_device_resident_jacobian(lib):
     assert np.linalg.norm(r) < 1e-9 * norms[0]
 
 
-def test_mpsa_reconstruction_eta_is_refused_not_ignored(lib):
-    g = pa.CartGrid([3, 3], [1.0, 1.0])
+def test_mpsa_reconstruction_eta(lib):
+    """``reconstruction_eta`` (mpsa.py:185, 757-761): the displacement traces are reconstructed at another point than
+    the continuity point -- the trace matrices change, stress / bound_stress do not; against the oracle (whose
+    hf_eta form is pinned to the reference by the mpsa_hfeta_* fixtures).  Where it is not covered it is refused."""
+    from oracle import mpsa_oracle as so
+
+    g = pa.StructuredTriangleGrid([3, 3], [1.0, 1.0])
     g.compute_geometry()
-    C = pa.FourthOrderTensor(np.ones(g.num_cells), np.ones(g.num_cells))
+    g = pa.perturb_interior_nodes(g, 0.05)
+    C = pa.FourthOrderTensor(np.ones(g.num_cells), 2.0 * np.ones(g.num_cells))
     bc = pa.BoundaryConditionVectorial(g)
     bf = g.get_all_boundary_faces()
-    bc.is_dir[:, bf] = True
-    bc.is_neu[:, bf] = False
-    ok = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "mpsa_eta": 0.0,
-                                              "reconstruction_eta": 0.0, "inverter": "python"})
-    pa.Mpsa("mechanics", library=lib).discretize(g, ok)
-    bad = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "mpsa_eta": 0.0,
-                                               "reconstruction_eta": 0.5})
+    bc.is_dir[:, bf[::2]] = True
+    bc.is_neu[:, bf[::2]] = False
+    out = {}
+    for name, extra in (("same", {"reconstruction_eta": 1.0 / 3.0}), ("other", {"reconstruction_eta": 0.1})):
+        data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "mpsa_eta": 1.0 / 3.0, **extra})
+        pa.Mpsa("mechanics", library=lib).discretize(g, data)
+        out[name] = data[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    raw = pa.grid_to_raw(g)
+    bcd = {"is_dir": bc.is_dir, "is_neu": bc.is_neu}
+    ora = so.discretize(raw, C.values, bcd, eta=1.0 / 3.0, hf_eta=0.1)
+    for k in ("stress", "bound_stress"):
+        assert abs(out["other"][k] - out["same"][k]).max() == 0.0
+    for k in ("bound_displacement_cell", "bound_displacement_face"):
+        assert abs(out["other"][k] - out["same"][k]).max() > 1e-3  # it does change the traces
+        assert abs(out["other"][k] - ora[k]).max() <= 1e-12 * abs(ora[k]).max(), k
+    bad = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "mpsa_eta": 1.0 / 3.0,
+                                               "reconstruction_eta": 0.1, "specified_cells": np.array([0])})
     with pytest.raises(NotImplementedError, match="reconstruction_eta"):
         pa.Mpsa("mechanics", library=lib).discretize(g, bad)

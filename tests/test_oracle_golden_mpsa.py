@@ -13,7 +13,7 @@ TOL = 1e-10
 @pytest.mark.parametrize("name", mpsa_case_names())
 def test_mpsa_oracle_matches_reference(name):
     c = MpsaCase(name)
-    out = so.discretize(c.grid, c.stiffness, c.bc, eta=c.eta_sub if c.eta_sub is not None else c.eta)
+    out = so.discretize(c.grid, c.stiffness, c.bc, eta=c.eta_sub if c.eta_sub is not None else c.eta, hf_eta=c.hf_eta)
     for k in MPSA_KEYS:
         if k not in c.ref:
             continue
