@@ -409,10 +409,37 @@ typedef struct {
   int (*exchange_halo)(void* user, double* d_x, void* stream);
   int (*allreduce_sum)(void* user, double* d_vals, int count, void* stream);
   void* user;
+  /* Transport of the coupled hierarchy (pfv_amg_setup_sharded; may be NULL for every other call).  The library
+   * owns the halo plans of all levels and packs / unpacks itself; the transport only moves packed buffers:
+   *   sendrecv(user, n_peers, peers, d_send, send_ptr, d_recv, recv_ptr, stream): to peer p go the doubles
+   *     d_send[send_ptr[p] .. send_ptr[p+1]), from it arrive d_recv[recv_ptr[p] .. recv_ptr[p+1])
+   *     (ncclGroupStart / ncclSend + ncclRecv per peer / ncclGroupEnd); the offset arrays are host memory, valid
+   *     during the call only;
+   *   allgather(user, d_send, d_recv, bytes_per_rank, stream): rank r's bytes_per_rank bytes land at
+   *     d_recv + r * bytes_per_rank on every rank (ncclAllGather). */
+  int (*sendrecv)(void* user, int n_peers, const int32_t* peers, const double* d_send, const int64_t* send_ptr,
+                  double* d_recv, const int64_t* recv_ptr, void* stream);
+  int (*allgather)(void* user, const void* d_send, void* d_recv, int64_t bytes_per_rank, void* stream);
 } pfv_shard_hooks;
 pfv_status pfv_solve_sharded(pfv_ctx* h, int method, double rtol, int maxit, int64_t n_own,
                              const pfv_shard_hooks* hooks, double* d_work, double* d_x_owned,
                              pfv_solve_info* info);
+
+/* Coupled hierarchy of a sharded solve (instead of pfv_amg_setup(n_own), whose block hierarchy ignores the
+ * couplings between ranks and pays for it in iterations): every level keeps the columns of the unknowns other ranks
+ * own (aggregates never cross a rank boundary; the Galerkin product of the owned rows carries the halo columns
+ * along, renamed to the owner's aggregates), smoothing and residual products see current halo values (one
+ * point-to-point exchange before each), and from the first level with at most PFV_AMG_GATHER_ROWS (default 32768)
+ * rows in total the rows of all ranks are gathered once (allgather) and every rank continues with the same
+ * replicated hierarchy -- per cycle one allgather of that level's right-hand side, no further communication.
+ * The plan of the finest level is given in CELLS (bs unknowns each travel): send_idx[send_ptr[p] ..) are the owned
+ * cells peer p needs, in the order it expects them; recv_pos[recv_ptr[p] ..) the local cells (>= n_own / bs) its
+ * values land in, in the order it sends them.  Every rank calls this (it is a collective of the transport);
+ * the hooks (all four entries) must stay valid until the next setup or the handle's end.  The reference has no
+ * distributed path (models/solution_strategy.py:830-884 solves on one process). */
+pfv_status pfv_amg_setup_sharded(pfv_ctx* h, int64_t n_own, const pfv_shard_hooks* hooks, int rank, int world,
+                                 int n_peers, const int32_t* peers, const int64_t* send_ptr,
+                                 const int32_t* send_idx, const int64_t* recv_ptr, const int32_t* recv_pos);
 
 /* The two hooks served natively over RCCL (xGMI), no Python in the iteration (csrc/rccl_hooks.inc):
  * pack kernel -> ncclGroupStart / ncclSend + ncclRecv per neighbour / ncclGroupEnd -> unpack kernel, and

@@ -36,7 +36,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc", "pfv_mpsa_set_subface_bc",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_setup_sharded", "pfv_amg_apply_device", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc", "pfv_mpsa_set_subface_bc",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
     "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces", "pfv_solve_sharded", "pfv_tpfa_transmissibility_ad",
     "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
@@ -70,9 +70,16 @@ HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)            # 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)  # (user, d_vals, count, stream)
 
 
+# (user, n_peers, peers, d_send, send_ptr, d_recv, recv_ptr, stream) / (user, d_send, d_recv, bytes_per_rank, stream)
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int64),
+                          C.c_void_p, C.POINTER(C.c_int64), C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
 class ShardHooks(C.Structure):
     """pfv_shard_hooks of include/porefv.h."""
-    _fields_ = [("exchange_halo", HALO_FN), ("allreduce_sum", ALLREDUCE_FN), ("user", C.c_void_p)]
+    _fields_ = [("exchange_halo", HALO_FN), ("allreduce_sum", ALLREDUCE_FN), ("user", C.c_void_p),
+                ("sendrecv", SENDRECV_FN), ("allgather", ALLGATHER_FN)]
 
 
 class PorefvError(RuntimeError):
@@ -134,6 +141,9 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_reset_stream.restype = C.c_int
     lib.pfv_amg_setup.argtypes = [_h, C.c_int64]
     lib.pfv_amg_setup.restype = C.c_int
+    lib.pfv_amg_setup_sharded.argtypes = [_h, C.c_int64, C.POINTER(ShardHooks), C.c_int, C.c_int, C.c_int, _ip, _lp, _ip,
+                                          _lp, _ip]
+    lib.pfv_amg_setup_sharded.restype = C.c_int
     lib.pfv_amg_apply_device.argtypes = [_h, C.c_void_p, C.c_void_p]
     lib.pfv_amg_apply_device.restype = C.c_int
     lib.pfv_biot_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int64, _ip, C.c_int]
@@ -875,6 +885,26 @@ class Context:
     def amg_setup(self, n_own: int = 0):
         """AMG hierarchy of the leading n_own x n_own block of the assembled system (0 = all of it)."""
         self._check(self.lib.pfv_amg_setup(self._h, int(n_own)))
+
+    def amg_setup_sharded(self, n_own: int, hooks: "ShardHooks", rank: int, world: int, peers, send_lists, recv_lists):
+        """Coupled hierarchy of a sharded solve (pfv_amg_setup_sharded): ``send_lists[i]`` are the owned CELLS peer
+        ``peers[i]`` needs (in the order it expects them), ``recv_lists[i]`` the local cells (>= n_own / bs) its values
+        land in.  A collective: every rank of the group calls it.  ``hooks`` must carry sendrecv and allgather and is
+        kept alive by this handle until the next setup."""
+        peers = np.ascontiguousarray(peers, dtype=np.int32)
+        sp = np.zeros(len(peers) + 1, dtype=np.int64)
+        rp = np.zeros(len(peers) + 1, dtype=np.int64)
+        for i in range(len(peers)):
+            sp[i + 1] = sp[i] + len(send_lists[i])
+            rp[i + 1] = rp[i] + len(recv_lists[i])
+        cat = lambda ls: (np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int32) for a in ls]), dtype=np.int32)
+                          if len(ls) else np.zeros(0, dtype=np.int32))
+        si, rpos = cat(send_lists), cat(recv_lists)
+        self._coupled_hooks = hooks  # (the C side copies the struct; the callbacks behind it must outlive the hierarchy)
+        self._check(self.lib.pfv_amg_setup_sharded(
+            self._h, int(n_own), C.byref(hooks), int(rank), int(world), int(len(peers)),
+            peers.ctypes.data_as(_ip), sp.ctypes.data_as(_lp), si.ctypes.data_as(_ip), rp.ctypes.data_as(_lp),
+            rpos.ctypes.data_as(_ip)))
 
     def amg_apply_device(self, r_ptr: int, z_ptr: int):
         """z = V-cycle(r) on device vectors (length of the block given to amg_setup)."""

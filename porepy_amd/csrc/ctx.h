@@ -3,6 +3,8 @@
 #include "../../include/porefv.h"
 #include "backend.h"
 
+#include <algorithm>
+#include <functional>
 #include <memory>
 #include <vector>
 

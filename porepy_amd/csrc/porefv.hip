@@ -1312,6 +1312,7 @@ pfv_status pfv_amg_setup(pfv_ctx* h, int64_t n_own) {
     auto s = h->stream;
     if (!h->amg_block) h->amg_block = std::make_unique<pfv::Amg>();
     h->amg_block->valid = false;
+    h->amg_block->dist.reset();  // (a coupled hierarchy of an earlier pfv_amg_setup_sharded)
     const pfv::CsrPattern* P = h->active.P;
     const double* val = h->active.val;
     if (n_own < n) {
@@ -1365,11 +1366,77 @@ pfv_status pfv_amg_setup(pfv_ctx* h, int64_t n_own) {
   });
 }
 
+pfv_status pfv_amg_setup_sharded(pfv_ctx* h, int64_t n_own, const pfv_shard_hooks* hooks, int rank, int world,
+                                 int n_peers, const int32_t* peers, const int64_t* send_ptr,
+                                 const int32_t* send_idx, const int64_t* recv_ptr, const int32_t* recv_pos) {
+  return guarded(h, [&] {
+    require(h->active.valid, "assemble first");
+    const int bs = h->active_bs;
+    const int64_t n = h->active.n;
+    require(n_own > 0 && n_own <= n && n_own % bs == 0 && n % bs == 0, "n_own out of range");
+    require(hooks && hooks->sendrecv && hooks->allgather, "the sendrecv and allgather hooks are required");
+    require(world >= 1 && rank >= 0 && rank < world, "bad rank / world");
+    require(n_peers >= 0 && (n_peers == 0 || (peers && send_ptr && recv_ptr)), "bad halo plan");
+    const int64_t own_cells = n_own / bs, loc_cells = n / bs;
+    auto plan = std::make_unique<pfv::AmgPlan>();
+    plan->n_peers = n_peers;
+    plan->peers.assign(peers, peers + n_peers);
+    plan->send_ptr.assign(1, 0);
+    plan->recv_ptr.assign(1, 0);
+    if (n_peers > 0) {
+      plan->send_ptr.assign(send_ptr, send_ptr + n_peers + 1);
+      plan->recv_ptr.assign(recv_ptr, recv_ptr + n_peers + 1);
+    }
+    require(plan->send_ptr.front() == 0 && plan->recv_ptr.front() == 0, "halo plan: offsets must start at 0");
+    for (int p = 0; p < n_peers; ++p) {
+      require(plan->send_ptr[p + 1] >= plan->send_ptr[p] && plan->recv_ptr[p + 1] >= plan->recv_ptr[p],
+              "halo plan: offsets must be non-decreasing");
+      require(peers[p] >= 0 && peers[p] < world && peers[p] != rank, "peer out of range");
+    }
+    const int64_t ns = plan->send_ptr.back(), nr = plan->recv_ptr.back();
+    require((ns == 0 || send_idx) && (nr == 0 || recv_pos), "halo plan: index lists missing");
+    for (int64_t k = 0; k < ns; ++k) require(send_idx[k] >= 0 && send_idx[k] < own_cells, "halo plan: send index is not an owned cell");
+    for (int64_t k = 0; k < nr; ++k)
+      require(recv_pos[k] >= own_cells && recv_pos[k] < loc_cells, "halo plan: receive position is not a halo cell");
+    require(nr == loc_cells - own_cells, "halo plan: every halo cell must be received exactly once");
+    plan->h_send_idx.assign(send_idx, send_idx + ns);
+    plan->h_recv_pos.assign(recv_pos, recv_pos + nr);
+    plan->n_own = own_cells;
+    plan->n_halo = loc_cells - own_cells;
+    pfv::amg_plan_upload(*h, *plan);
+    if (!h->amg_block) h->amg_block = std::make_unique<pfv::Amg>();
+    pfv::Amg& amg = *h->amg_block;
+    amg.valid = false;
+    if (!amg.dist) amg.dist = std::make_unique<pfv::AmgDist>();
+    amg.dist->hooks = *hooks;
+    amg.dist->rank = rank;
+    amg.dist->world = world;
+    amg.dist->plan.clear();
+    amg.dist->plan.push_back(std::move(plan));
+    // the rows of the owned unknowns over all local columns (owned + halo)
+    const pfv::CsrPattern& P = *h->active.P;
+    pfv::CsrPattern& V = amg.dist->rows0;  // (borrows the index arrays: see ~AmgDist)
+    V.nrows = n_own;
+    V.ncols = n;
+    V.nnz = P.nnz;
+    V.max_row = P.max_row;
+    V.indptr.p = P.indptr.p;
+    V.indices.p = P.indices.p;
+    pfv::amg_setup(*h, amg, V, h->active.val, bs, nullptr, nullptr);
+    h->stats.amg_setup_ms = amg.setup_ms;
+    h->stats.amg_operator_complexity = amg.op_complexity;
+    h->stats.amg_levels = (int64_t)(amg.nlev + (amg.dist->glob ? amg.dist->glob->nlev - 1 : 0));
+    h->stats.amg_coarsest_rows = amg.dist->gN;
+    h->stats.amg_maps_reused = 0;
+  });
+}
+
 pfv_status pfv_amg_apply_device(pfv_ctx* h, const double* d_r, double* d_z) {
   return guarded(h, [&] {
     require(h->amg_block && h->amg_block->valid, "pfv_amg_setup first");
     require(d_r && d_z && d_r != d_z, "bad vectors");
-    pfv::amg_cycle(*h, *h->amg_block, 0, d_r, d_z);
+    if (h->amg_block->dist) pfv::amg_apply_dist(*h, *h->amg_block, d_r, d_z);
+    else pfv::amg_cycle(*h, *h->amg_block, 0, d_r, d_z);
   });
 }
 

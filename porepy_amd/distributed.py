@@ -185,6 +185,9 @@ class HaloPlan:
             if g.size:
                 self.recv[q] = torch.from_numpy((lp.n_own + np.flatnonzero(lp.halo_owner == q)).astype(np.int64))
         self.bytes_per_exchange = 8 * sum(int(v.numel()) for v in self.send.values())
+        # the same lists in cells, on the host: the coupled hierarchy derives the plans of its coarse levels from them
+        self.send_cells = {p: v.numpy().astype(np.int32) for p, v in self.send.items()}
+        self.recv_cells = {q: v.numpy().astype(np.int32) for q, v in self.recv.items()}
 
     def to(self, device):
         self.send = {k: v.to(device) for k, v in self.send.items()}
@@ -302,15 +305,126 @@ class ShardedMpfa:
             self.dist.all_reduce(t)
         return t
 
+    # ---- coupled AMG hierarchy (pfv_amg_setup_sharded): the transport of its packed buffers
+    def _view(self, ptr: int, nbytes: int):
+        """uint8 tensor over nbytes of library-owned memory at ptr (host memory of the emulation build, device memory
+        of the HIP build)."""
+        import ctypes as C
+
+        torch = self.torch
+        if nbytes == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.device)
+        if self.device.type == "cpu":
+            return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)))
+
+        class _Mem:  # (torch wraps foreign device memory through the array interface)
+            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        return torch.as_tensor(_Mem(), device=self.device)
+
+    def _torch_transport(self):
+        """sendrecv / allgather of pfv_shard_hooks served by torch.distributed (the gloo / CPU test path, and any group
+        the native RCCL transport cannot serve).  Blocking: the data is in place when the hook returns."""
+        torch, dist = self.torch, self.dist
+        world = dist.get_world_size() if dist is not None else 1
+        stage = self.device.type == "cuda" and dist is not None and dist.get_backend() == "gloo"
+        failure = self._hook_failures = []
+
+        def sendrecv(_user, n_peers, peers, d_send, send_ptr, d_recv, recv_ptr, _stream):
+            try:
+                if self.device.type == "cuda":
+                    self.ctx.sync()
+                ops, landing = [], []
+                for i in range(n_peers):
+                    ns, nr = send_ptr[i + 1] - send_ptr[i], recv_ptr[i + 1] - recv_ptr[i]
+                    if nr:
+                        rb = self._view(int(d_recv) + 8 * recv_ptr[i], 8 * nr).view(torch.float64)
+                        buf = torch.empty(nr, dtype=torch.float64) if stage else rb
+                        landing.append((rb, buf))
+                        ops.append(dist.P2POp(dist.irecv, buf, int(peers[i])))
+                    if ns:
+                        sb = self._view(int(d_send) + 8 * send_ptr[i], 8 * ns).view(torch.float64)
+                        ops.append(dist.P2POp(dist.isend, sb.cpu() if stage else sb, int(peers[i])))
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+                for rb, buf in landing:
+                    if buf is not rb:
+                        rb.copy_(buf)
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                return 0
+            except BaseException as e:  # must not propagate through the C frames
+                failure.append(e)
+                return 1
+
+        def allgather(_user, d_send, d_recv, nbytes, _stream):
+            try:
+                if self.device.type == "cuda":
+                    self.ctx.sync()
+                src = self._view(int(d_send), nbytes)
+                dst = self._view(int(d_recv), nbytes * world)
+                if world == 1:
+                    dst.copy_(src)
+                elif stage:
+                    parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, src.cpu())
+                    dst.copy_(torch.cat(parts))
+                else:
+                    dist.all_gather(list(dst.chunk(world)), src)
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                return 0
+            except BaseException as e:
+                failure.append(e)
+                return 1
+
+        hooks = _lib.ShardHooks()
+        hooks.sendrecv = _lib.SENDRECV_FN(sendrecv)
+        hooks.allgather = _lib.ALLGATHER_FN(allgather)
+        self._transport_callbacks = (hooks.sendrecv, hooks.allgather)  # keep the trampolines alive
+        return hooks
+
+    def amg_setup(self, coupled: bool = True, native=None):
+        """Hierarchy of this rank's preconditioner.  coupled (default): the levels keep the couplings to the unknowns of
+        other ranks -- halo exchange before the smoothing / residual products, coarse levels gathered and replicated
+        from PFV_AMG_GATHER_ROWS rows down (pfv_amg_setup_sharded): the iteration count of the one-process solve.
+        coupled = False: block Jacobi across ranks (pfv_amg_setup(n_own)), no communication in the preconditioner,
+        more iterations.  A collective when coupled."""
+        if not coupled:
+            self.ctx.amg_setup(self.n_own)
+            self._amg_ready = "block"
+            return
+        import ctypes as C
+
+        dist = self.dist
+        world = dist.get_world_size() if dist is not None else 1
+        rank = dist.get_rank() if dist is not None else 0
+        if native is not None:
+            hooks = _lib.ShardHooks()
+            self.ctx._check(self.ctx.lib.pfv_rccl_hooks(native._c, C.byref(hooks)))
+        else:
+            hooks = self._torch_transport()
+        peers = sorted(set(self.plan.send_cells) | set(self.plan.recv_cells))
+        empty = np.zeros(0, dtype=np.int32)
+        self.ctx.amg_setup_sharded(self.n_own, hooks, rank, world, peers,
+                                   [self.plan.send_cells.get(p, empty) for p in peers],
+                                   [self.plan.recv_cells.get(p, empty) for p in peers])
+        if getattr(self, "_hook_failures", None):
+            raise self._hook_failures[0]
+        self._amg_ready = "coupled-native" if native is not None else "coupled"
+
     def _spmv_owned(self, x_full, out_owned):
         self.plan.exchange(x_full)
         self.ctx.spmv_device_rows(self.system_matrix, self.n_own, x_full.data_ptr(), out_owned.data_ptr())
 
     def solve(self, method: str = "bicgstab", rtol: float = 1e-10, maxit: int = 20000, check_every: int = 10,
               precond: str = "jacobi", driver: str = "library"):
-        """Returns (x_owned as a torch tensor, info).  precond = "amg": every rank applies one V-cycle of
-        the aggregation AMG of its own diagonal block (owned cells x owned cells) -- block Jacobi
-        across ranks, no communication inside the preconditioner.
+        """Returns (x_owned as a torch tensor, info).  precond = "amg": one cycle of the coupled aggregation AMG
+        (``amg_setup``: every level exchanges its halo values, the coarse levels are gathered and replicated -- the
+        iteration count of the one-process solve); precond = "amg_block": every rank applies one V-cycle of the
+        hierarchy of its own diagonal block (owned cells x owned cells) -- block Jacobi across ranks, no
+        communication inside the preconditioner, more iterations.
 
         driver = "library" (default): the fused Krylov loop of the C ABI (``pfv_solve_sharded``: windowed
         SpMV with fused dot products, fused vector updates, scalars resident in HBM) calling back here
@@ -329,10 +443,10 @@ class ShardedMpfa:
         b = self._b[:n]
         dinv = 1.0 / self._diag[:n]
         f64 = dict(dtype=torch.float64, device=dev)
-        if precond == "amg":
-            if not self._amg_ready:
-                self.ctx.amg_setup(n)
-                self._amg_ready = True
+        if precond in ("amg", "amg_block"):
+            want = "block" if precond == "amg_block" else "coupled"
+            if self._amg_ready != want:
+                self.amg_setup(coupled=precond == "amg")
             check_every = 1
 
             def apply_M(vec):
@@ -344,7 +458,7 @@ class ShardedMpfa:
             def apply_M(vec):
                 return vec * dinv
         else:
-            raise ValueError("precond must be 'jacobi' or 'amg'")
+            raise ValueError("precond must be 'jacobi', 'amg' or 'amg_block'")
         x = torch.zeros(n, **f64)
         r = b.clone()
         full = torch.zeros(self.n_loc, **f64)   # owned + halo staging vector for the SpMV input
@@ -521,16 +635,17 @@ class ShardedMpfa:
     def _solve_library(self, method, rtol, maxit, precond):
         torch = self.torch
         n, nloc, dev = self.n_own, self.n_loc, self.device
-        if precond not in ("jacobi", "amg"):
-            raise ValueError("precond must be 'jacobi' or 'amg'")
+        if precond not in ("jacobi", "amg", "amg_block"):
+            raise ValueError("precond must be 'jacobi', 'amg' or 'amg_block'")
         import os
 
         native = self.rccl_transport() if os.environ.get("PFV_SHARDED_TRANSPORT", "rccl") == "rccl" else None
+        want = {"amg": "coupled-native" if native is not None else "coupled", "amg_block": "block"}.get(precond)
         if native is not None:
             # the handle keeps its own stream: nothing of torch takes part in the iteration
-            if precond == "amg" and not self._amg_ready:
-                self.ctx.amg_setup(n)
-                self._amg_ready = True
+            if want and self._amg_ready != want:
+                self.amg_setup(coupled=precond == "amg", native=native)
+            precond = "amg" if want else precond
             work = torch.empty(2 * nloc + 2, dtype=torch.float64, device=dev)
             x = torch.empty(n, dtype=torch.float64, device=dev)
             torch.cuda.current_stream(dev).synchronize()  # the buffers exist before the handle's stream uses them
@@ -542,9 +657,9 @@ class ShardedMpfa:
             info["transport"] = "rccl (native hooks)"
             return x, info
         self._use_torch_stream()
-        if precond == "amg" and not self._amg_ready:
-            self.ctx.amg_setup(n)
-            self._amg_ready = True
+        if want and self._amg_ready != want:
+            self.amg_setup(coupled=precond == "amg")
+        precond = "amg" if want else precond
         work = torch.empty(2 * nloc + 2, dtype=torch.float64, device=dev)
         x = torch.empty(n, dtype=torch.float64, device=dev)
         views = {work.data_ptr(): work[:nloc], work.data_ptr() + 8 * nloc: work[nloc:2 * nloc]}
