@@ -420,8 +420,10 @@ def main():
     ap.add_argument("--n-side", type=int, default=69, help="lattice cells per side (6 tets each)")
     ap.add_argument("--rtol", type=float, default=1e-13,
                     help="relative tolerance on the TRUE residual; 1e-13 is what 1e-10 field parity needs (SURVEY 8(d))")
-    ap.add_argument("--precond", choices=("amg", "jacobi"), default="amg",
-                    help="preconditioner of the BiCGStab solve: aggregation-AMG V-cycle (default) or Jacobi")
+    ap.add_argument("--precond", choices=("amg", "amg_block", "jacobi"), default="amg",
+                    help="preconditioner of the BiCGStab solve: aggregation-AMG cycle (default; N > 1: the coupled "
+                         "hierarchy, halo exchange on every level), amg_block (N > 1 only: block Jacobi across ranks, "
+                         "the hierarchy of each rank's diagonal block) or Jacobi")
     ap.add_argument("--cpu-n-side", type=int, default=32,
                     help="lattice side of the reference's CPU run (32 = 196 608 cells, BASELINE configs[1] size: ~2 min)")
     ap.add_argument("--cpu-port-n-side", type=int, default=16, help="size of the oracle-port fallback")
@@ -586,7 +588,7 @@ def main():
         "achieved = SURVEY 8(d) CSR bytes (12 B per entry) / time; the kernel itself streams ~10 B per entry "
         "(16-bit window-local column indices)", "krylov",
         {"streamed_GBs": (10.0 * nnzA + 4.0 * (nloc + 1) + 8.0 * nloc + 12.0 * nloc * 0.36) / (spmv_ms * 1e-3) / 1e9}))
-    if args.precond == "amg" and os.environ.get("PFV_AMG_FP32", "1") != "0":
+    if args.precond in ("amg", "amg_block") and os.environ.get("PFV_AMG_FP32", "1") != "0":
         sm_ms = ctx.time_kernel(3, reps=50)
         st_amg = ctx.stats()
         nnzS = int(st_amg.get("amg_level0_nnz", 0)) or nnzA  # the cycle's finest level: the strength-filtered operator
@@ -751,7 +753,11 @@ def main():
                        "amg": ({"levels": st["amg_levels"], "operator_complexity": st["amg_operator_complexity"],
                                 "setup_ms": st["amg_setup_ms"], "coarsest_rows": st["amg_coarsest_rows"],
                                 "filter_theta": st.get("amg_filter_theta"), "level0_entries": st.get("amg_level0_nnz")}
-                               if args.precond == "amg" else None),
+                               if args.precond in ("amg", "amg_block") else None),
+                       "sharded_hierarchy": (None if sh is None else
+                                             {"amg": "coupled (halo exchange on every level, coarse levels gathered and "
+                                                     "replicated: pfv_amg_setup_sharded)",
+                                              "amg_block": "block Jacobi across ranks (pfv_amg_setup(n_own))"}.get(args.precond)),
                        "solve_on_renumbered_copy": bool(st.get("solve_renumbered", 0)),
                        "iterations": info["iterations"], "converged": info["converged"],
                        "true_rel_residual": res_true, "field_error": field,
@@ -759,7 +765,8 @@ def main():
                        "transport": (info.get("transport") if isinstance(info, dict) else None),
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} z-slab subdomains (1 lattice layer of halo cells recomputed per cut), assembly "
-                       "without collectives, BiCGStab with RCCL point-to-point halo exchange + fused all-reduces"},
+                       "without collectives, BiCGStab with RCCL point-to-point halo exchange + fused all-reduces; "
+                       "AMG: per level and visit 2 point-to-point halo exchanges, one all-gather at the gathered level"},
             "roofline": roofline, "roofline_kernels": kernels[1:], "kernel_ms_per_step": per_step_ms,
             "hbm_triad_measured_GBs": triad_gbs, "hbm_read_stream_measured_GBs": read_gbs,
             "assembly": assembly, "operator_api": opapi, "cpu_baseline": cpu, "config_c2": c2, "config_c4": c4,

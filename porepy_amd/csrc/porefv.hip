@@ -1641,7 +1641,7 @@ pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms) {
       pfv::Amg* amg = (h->amg && h->amg->valid) ? h->amg.get() : h->amg_block.get();  // single-GPU / sharded
       require(amg && amg->valid && amg->nlev > 0, "no AMG hierarchy (solve with PFV_PRECOND_AMG first)");
       pfv::AmgLevel& L = *amg->lev[0];
-      const size_t n = (size_t)L.n;
+      const size_t n = (size_t)std::max(L.n, L.m);  // (coupled hierarchy: the input carries the halo entries)
       double* x = h->kry[7].ensure(n);
       double* y = h->kry[8].ensure(n);
       double* b = h->kry[6].ensure(n);
