@@ -458,6 +458,34 @@ pfv_status pfv_rccl_stats(pfv_rccl_comm* c, int64_t* exchanges, int64_t* allredu
 const char* pfv_rccl_last_error(pfv_rccl_comm* c);
 void pfv_rccl_comm_destroy(pfv_rccl_comm* c);
 
+/* ---- Device-resident CSR matrices and the sparse algebra of the step after discretize --------
+ * What MergedOperator.parse (numerics/ad/ad_utils.py:597-663 -> matrix_operations.csr_matrix_from_sparse_blocks) and the
+ * scipy products / sums of the operator tree (assembled by EquationSystem.assemble, numerics/ad/equation_system.py:1579)
+ * do on the host, kept in HBM: a pfv_csr is created from a discretization matrix of a handle without a host copy
+ * (pfv_csr_from_matrix) or uploaded once (projections, divergences: pfv_csr_from_host), combined block-diagonally, by
+ * products and by sums, and handed to pfv_solve as the active system (pfv_csr_set_system).  scipy's conventions, so
+ * that results compare entry by entry: rows sorted by column without duplicates (required of inputs, guaranteed of
+ * outputs), accumulation in the order of csr_matmat / csr_binop_csr with every product rounded on its own (same bits),
+ * entries that come out exactly zero are not stored.  A pfv_csr belongs to the handle it was created on (same
+ * device for all operands) and must be freed before that handle is destroyed. */
+typedef struct pfv_csr pfv_csr;
+pfv_status pfv_csr_from_host(pfv_ctx* h, int64_t nrows, int64_t ncols, const int32_t* indptr, const int32_t* indices,
+                             const double* values, pfv_csr** out);
+/* device-to-device copy of matrix `which` (pfv_matrix_id) of handle src */
+pfv_status pfv_csr_from_matrix(pfv_ctx* h, pfv_ctx* src, int which, pfv_csr** out);
+pfv_status pfv_csr_block_diag(pfv_ctx* h, int n, const pfv_csr* const* blocks, pfv_csr** out);
+pfv_status pfv_csr_matmul(pfv_ctx* h, const pfv_csr* A, const pfv_csr* B, pfv_csr** out);   /* A B; PFV_ERR_UNSUPPORTED
+                                                                     when more than 4096 products feed one row */
+pfv_status pfv_csr_axpby(pfv_ctx* h, double alpha, const pfv_csr* A, double beta, const pfv_csr* B, pfv_csr** out);
+pfv_status pfv_csr_scale(pfv_csr* A, const double* row_scale, const double* col_scale);   /* in place; host arrays or NULL */
+pfv_status pfv_csr_spmv(const pfv_csr* A, const double* x, double* y);                     /* host vectors */
+pfv_status pfv_csr_spmv_device(const pfv_csr* A, const double* d_x, double* d_y);
+pfv_status pfv_csr_info(const pfv_csr* A, int64_t* nrows, int64_t* ncols, int64_t* nnz);
+pfv_status pfv_csr_get(const pfv_csr* A, int32_t* indptr, int32_t* indices, double* values);  /* any may be NULL */
+/* (A, rhs) become the active system of h -- what pfv_solve / pfv_amg_setup work on -- without leaving the device */
+pfv_status pfv_csr_set_system(pfv_ctx* h, const pfv_csr* A, const double* rhs, int rhs_on_device);
+void pfv_csr_free(pfv_csr* A);
+
 /* run this handle's work on an externally owned HIP stream (hipStream_t passed as void*, e.g.
  * torch.cuda.current_stream().cuda_stream) so that it is ordered with the caller's kernels and
  * RCCL collectives.  NULL is the legacy default stream (what torch's default stream is) -- the

@@ -1722,3 +1722,4 @@ pfv_status pfv_debug_copy(pfv_ctx* h, int which, double* dst, int64_t count) {
 }  // extern "C"
 
 #include "rccl_hooks.inc"
+#include "csr_algebra.inc"

@@ -1,0 +1,216 @@
+"""Device-resident sparse matrices: the algebra of the step AFTER ``discretize``.
+
+In the reference a Newton iteration on a fixed grid re-does, on the host, what ``MergedOperator.parse``
+(``numerics/ad/ad_utils.py:597-663``: the matrices of all subdomains concatenated block-diagonally through
+``matrix_operations.csr_matrix_from_sparse_blocks``) and the operator tree above it spell out in scipy: products with
+projections and divergences, diagonal scalings, sums (``EquationSystem.assemble``, ``numerics/ad/equation_system.py:1579``).
+A ``DeviceCsr`` is such a matrix kept in HBM behind the C ABI (``pfv_csr_*``, ``csrc/csr_algebra.inc``): made from the
+discretization matrices of a handle without a host copy, combined with ``@``, ``+``, ``-``, scalar ``*``,
+``block_diag`` and row / column scalings, multiplied with vectors, handed to the device solver as its system --
+a discretization matrix never crosses PCIe.  The results follow scipy's conventions bit for bit (sorted rows,
+products and sums accumulated in scipy's order, exact zeros dropped), which is how the tests pin them.
+
+The operator TREE (``pp.ad`` parsing, variables, time stepping) stays in the reference: its AD layer checks
+``isinstance(m, scipy.sparse.spmatrix)`` and would not accept a foreign matrix type; what is built here is the sparse
+algebra a device-side evaluation of that tree needs."""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceCsr:
+    """One CSR matrix (FP64 values, int32 indices) resident on the device of ``context``."""
+
+    __array_priority__ = 20.0
+
+    def __init__(self, context: "_lib.Context", handle):
+        self.ctx = context
+        self._c = handle
+        context._csr_refs.append(weakref.ref(self))
+
+    # ---- construction ------------------------------------------------------------------------------------------
+    @classmethod
+    def from_scipy(cls, A, context: "_lib.Context") -> "DeviceCsr":
+        import scipy.sparse as sps
+
+        A = sps.csr_matrix(A)
+        if not A.has_canonical_format:
+            A = A.copy()
+            A.sum_duplicates()
+        if A.nnz >= 2 ** 31:
+            raise ValueError("more than 2^31 matrix entries")
+        ip = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        ix = np.ascontiguousarray(A.indices, dtype=np.int32)
+        dv = np.ascontiguousarray(A.data, dtype=np.float64)
+        out = _lib._h()
+        context._check(context.lib.pfv_csr_from_host(context._h, A.shape[0], A.shape[1], _lib._ptr(ip, _lib._ip),
+                                                     _lib._ptr(ix, _lib._ip), _lib._ptr(dv, _lib._dp), C.byref(out)))
+        return cls(context, out)
+
+    @classmethod
+    def from_discretization(cls, source: "_lib.Context", which: int, context: "_lib.Context | None" = None) -> "DeviceCsr":
+        """Device-to-device copy of discretization matrix ``which`` (``_lib.MAT_*``) of ``source``."""
+        context = source if context is None else context
+        out = _lib._h()
+        context._check(context.lib.pfv_csr_from_matrix(context._h, source._h, int(which), C.byref(out)))
+        return cls(context, out)
+
+    @classmethod
+    def from_any(cls, m, context: "_lib.Context") -> "DeviceCsr":
+        """A ``DeviceCsr`` as it is; a lazily fetched discretization matrix (``lazy.LazyCsr``) that has not left the
+        device yet by a device-to-device copy; anything scipy understands by upload."""
+        from .lazy import LazyCsr
+
+        if isinstance(m, DeviceCsr):
+            return m
+        if isinstance(m, LazyCsr) and not m.materialized and m._post is None and m._ctx is not None:
+            return cls.from_discretization(m._ctx, m._which, context)
+        return cls.from_scipy(m.tocsr() if isinstance(m, LazyCsr) else m, context)
+
+    # ---- facts -------------------------------------------------------------------------------------------------
+    def _info(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self.ctx._check(self.ctx.lib.pfv_csr_info(self._c, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
+    @property
+    def shape(self):
+        r, c, _ = self._info()
+        return (r, c)
+
+    @property
+    def nnz(self) -> int:
+        return self._info()[2]
+
+    ndim = 2
+
+    # ---- algebra -----------------------------------------------------------------------------------------------
+    def _binary(self, fn, *args):
+        out = _lib._h()
+        self.ctx._check(fn(self.ctx._h, *args, C.byref(out)))
+        return DeviceCsr(self.ctx, out)
+
+    def __matmul__(self, other):
+        if isinstance(other, DeviceCsr):
+            return self._binary(self.ctx.lib.pfv_csr_matmul, self._c, other._c)
+        x = np.asarray(other)
+        if x.ndim != 1 or x.shape[0] != self.shape[1]:
+            raise ValueError("DeviceCsr @ x expects a vector of matching length (or another DeviceCsr)")
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(self.shape[0])
+        self.ctx._check(self.ctx.lib.pfv_csr_spmv(self._c, _lib._ptr(x, _lib._dp), _lib._ptr(y, _lib._dp)))
+        return y
+
+    dot = __matmul__
+
+    def matvec_device(self, x_ptr: int, y_ptr: int):
+        """y = A x on device vectors (raw addresses), on the stream of the owning handle."""
+        self.ctx._check(self.ctx.lib.pfv_csr_spmv_device(self._c, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+
+    def axpby(self, alpha: float, other: "DeviceCsr", beta: float) -> "DeviceCsr":
+        """alpha * self + beta * other."""
+        return self._binary(self.ctx.lib.pfv_csr_axpby, float(alpha), self._c, float(beta), other._c)
+
+    def __add__(self, other):
+        return self.axpby(1.0, other, 1.0)
+
+    def __sub__(self, other):
+        return self.axpby(1.0, other, -1.0)
+
+    def copy(self) -> "DeviceCsr":
+        return self.scaled()
+
+    def scaled(self, rows=None, cols=None) -> "DeviceCsr":
+        """diag(rows) @ self @ diag(cols) as a new matrix (either may be None)."""
+        out = block_diag([self])
+        r = None if rows is None else np.ascontiguousarray(rows, dtype=np.float64)
+        c = None if cols is None else np.ascontiguousarray(cols, dtype=np.float64)
+        if r is not None and r.shape != (self.shape[0],) or c is not None and c.shape != (self.shape[1],):
+            raise ValueError("scaling vector of the wrong length")
+        if r is not None or c is not None:
+            self.ctx._check(self.ctx.lib.pfv_csr_scale(out._c, None if r is None else _lib._ptr(r, _lib._dp),
+                                                       None if c is None else _lib._ptr(c, _lib._dp)))
+        return out
+
+    def __mul__(self, alpha):
+        if not np.isscalar(alpha):
+            return NotImplemented
+        return self.scaled(rows=np.full(self.shape[0], float(alpha)))
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self * -1.0
+
+    # ---- leaving the device ------------------------------------------------------------------------------------
+    def to_scipy(self):
+        import scipy.sparse as sps
+
+        nr, nc, nnz = self._info()
+        ip = np.empty(nr + 1, dtype=np.int32)
+        ix = np.empty(nnz, dtype=np.int32)
+        dv = np.empty(nnz, dtype=np.float64)
+        self.ctx._check(self.ctx.lib.pfv_csr_get(self._c, _lib._ptr(ip, _lib._ip), _lib._ptr(ix, _lib._ip),
+                                                 _lib._ptr(dv, _lib._dp)))
+        return sps.csr_matrix((dv, ix, ip), shape=(nr, nc))
+
+    tocsr = to_scipy
+
+    def as_system(self, rhs, context: "_lib.Context | None" = None, rhs_device_ptr: int | None = None):
+        """Make (self, rhs) the active system of ``context`` (default: the owning handle): ``context.solve(...)`` then
+        works on it.  The matrix moves device-to-device; ``rhs`` is a host array unless ``rhs_device_ptr`` is given."""
+        ctx = self.ctx if context is None else context
+        n = self.shape[0]
+        if rhs_device_ptr is not None:
+            ctx._check(ctx.lib.pfv_csr_set_system(ctx._h, self._c, C.c_void_p(rhs_device_ptr), 1))
+        else:
+            b = np.ascontiguousarray(rhs, dtype=np.float64)
+            if b.shape != (n,):
+                raise ValueError("right-hand side of the wrong length")
+            ctx._check(ctx.lib.pfv_csr_set_system(ctx._h, self._c, b.ctypes.data_as(C.c_void_p), 0))
+        ctx._user_n = n
+        return ctx
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c and getattr(self.ctx, "_h", None):
+            self.ctx.lib.pfv_csr_free(self._c)
+        self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __repr__(self):
+        r, c, z = self._info()
+        return f"<DeviceCsr {r}x{c}, {z} stored entries, on device>"
+
+
+def block_diag(mats, context: "_lib.Context | None" = None) -> DeviceCsr:
+    """Block-diagonal concatenation on the device: ``matrix_operations.csr_matrix_from_sparse_blocks`` of the reference,
+    i.e. what ``MergedOperator.parse`` returns for the discretization matrices of a list of subdomains."""
+    mats = list(mats)
+    if context is None:
+        context = next((m.ctx for m in mats if isinstance(m, DeviceCsr)), None)
+        if context is None:
+            raise ValueError("block_diag of host matrices needs a context")
+    dm = [DeviceCsr.from_any(m, context) for m in mats]
+    arr = (_lib._h * max(len(dm), 1))(*[m._c for m in dm])
+    out = _lib._h()
+    context._check(context.lib.pfv_csr_block_diag(context._h, len(dm), arr, C.byref(out)))
+    return DeviceCsr(context, out)
+
+
+def merged_matrix(discretization_data, keyword: str, matrix_key: str, context: "_lib.Context") -> DeviceCsr:
+    """``MergedOperator.parse`` on the device: the matrices ``data[DISCRETIZATION_MATRICES][keyword][matrix_key]`` of a
+    list of data dictionaries (one per subdomain, in the order of the operator's domains) as one block-diagonal
+    ``DeviceCsr``.  Lazily fetched matrices (``Mpfa(keyword, lazy=True)``) are copied device-to-device."""
+    from .params import DISCRETIZATION_MATRICES
+
+    return block_diag([d[DISCRETIZATION_MATRICES][keyword][matrix_key] for d in discretization_data], context)

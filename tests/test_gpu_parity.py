@@ -367,3 +367,12 @@ def test_interaction_region_with_more_than_64_subfaces(lib):
 
 def test_sliver_grids_take_the_iterative_refinement_path(lib):
     P.sliver_refinement(lib)
+
+
+@pytest.mark.parametrize("case", ["random_algebra", "input_checks", "discretization_to_system", "merged_subdomains"])
+def test_device_csr_algebra(lib, case):
+    """SURVEY §8 row N4 on the gfx950 library: products, sums and block diagonals bit-identical to scipy's, the flow
+    system assembled and solved without a discretization matrix leaving HBM (tests/_device_csr_cases.py)."""
+    from tests import _device_csr_cases as cases
+
+    getattr(cases, case)(lib)

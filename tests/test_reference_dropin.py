@@ -107,3 +107,20 @@ def test_thermo_hydro_mixed_dimensional_model_with_rebound_mpfa(variant):
     assert c["flow:3"] >= 1 and c["flow:2"] >= 2 and c["fourier_discretization:3"] >= 1 and c["fourier_discretization:2"] >= 2
     assert out["T_range"][1] - out["T_range"][0] > 1.0 and out["p_range"][1] - out["p_range"][0] > 0.5  # a non-trivial state
     assert max(out["x_rel_err"], out["T_rel_err"], out["p_rel_err"], out["A_rel_err"]) < 1e-10
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_merged_operator_parse_and_flux_products_on_the_device(variant):
+    """``MergedOperator.parse`` (numerics/ad/ad_utils.py:597-663) and the matrix products of the flux
+    expression formed by ``porepy_amd.DeviceCsr`` on the reference's mixed-dimensional model.  The device concatenation
+    of the reference's own blocks IS its ``parse`` result (bit for bit); with the blocks of the 3-D subdomain resident
+    on the device (never copied to the host) the merged matrices, the Jacobian blocks Div Flux and
+    Div BoundFlux P_mortar and the flux of a random state agree with scipy on the reference's matrices to the
+    parity tolerance of the discretization."""
+    out = run_script("_dropin_merged_script.py", variant, 600)
+    assert out["subdomains"] == 4 and out["dims"] == [3, 2, 1]
+    assert out["block_diag_bit_identical_to_reference_parse"] is True
+    assert all(v == "device" for v in out["where_the_blocks_were"]["dim3"].values())
+    assert max(out["merged_rel_err"].values()) < 1e-10
+    assert out["J_pp_rel_err"] < 1e-10 and out["J_pl_rel_err"] < 1e-10 and out["flux_rel_err"] < 1e-10
+    assert out["J_pp_shape"] == [100, 100] and out["J_pl_nnz"] > 0
