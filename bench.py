@@ -169,11 +169,34 @@ def _hash_normal(gid: np.ndarray, salt: int) -> np.ndarray:
     return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
 
 
-def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = None, strong: bool = False):
+def block_grid(world: int):
+    """(px, py, pz) with px * py * pz = world, as cubic as possible, the largest factor along z (the axis the cells are
+    numbered slowest in): 2 -> (1, 1, 2), 4 -> (1, 2, 2), 8 -> (2, 2, 2), 6 -> (1, 2, 3)."""
+    best = None
+    for px in range(1, world + 1):
+        if world % px:
+            continue
+        for py in range(px, world // px + 1):
+            if (world // px) % py:
+                continue
+            pz = world // (px * py)
+            if pz < py:
+                continue
+            cand = (pz - px, (px, py, pz))
+            if best is None or cand < best:
+                best = cand
+    return best[1]
+
+
+def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = None, strong: bool = False,
+                      blocks=None):
     """Rank `rank`'s share of the global box [0,1]x[0,1]x[0,layers*world/n] of n x n x (layers*world) lattice
-    cells (6 tetrahedra each): its n lattice layers plus one halo layer on each interior side,
+    cells (6 tetrahedra each): its lattice cells plus one halo layer on each interior side,
     built directly (no global grid), owned cells numbered first.  Geometry perturbation and the
     permeability field are functions of GLOBAL node / cell ids, so all ranks see one global problem.
+    Default: z-slabs.  ``blocks = (px, py, pz)`` (strong scaling only; px py pz = world): the one-GPU box cut into
+    px x py x pz blocks -- at 8 ranks every block of (2, 2, 2) has halo layers on 3 of its 6 sides (9 % more cells to
+    discretize than it owns) where an interior slab has them on both sides of its 8-9 layers (23 %).
     Returns (LocalProblem, K values (3,3,nloc), bc flags, bc values, source, eta)."""
     import porepy_amd as pa
     from porepy_amd import distributed as D
@@ -181,23 +204,43 @@ def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = N
     n = n_side
     lay = n if layers is None else int(layers)  # lattice layers owned by each rank (weak scaling)
     ktot = n if strong else lay * world
-    # layer boundaries of the ranks: weak = `lay` layers each (the box grows with the number of ranks),
-    # strong = the n layers of the one-GPU box split as evenly as possible
-    bounds = np.array([(r * ktot) // world for r in range(world + 1)]) if strong else lay * np.arange(world + 1)
-    if np.any(np.diff(bounds) < 1):
-        raise SystemExit("more ranks than lattice layers")
-    lo_k, hi_k = int(bounds[rank]), int(bounds[rank + 1])
-    k0, k1 = max(0, lo_k - 1), min(ktot, hi_k + 1)
-    nl = k1 - k0
-    g = pa.StructuredTetrahedralGrid([n, n, nl], [1.0, 1.0, nl / n])
+    dims = (n, n, ktot)
+    if blocks is None:
+        blocks = (1, 1, world)
+    blocks = tuple(int(p) for p in blocks)
+    if blocks[0] * blocks[1] * blocks[2] != world:
+        raise SystemExit("the block grid does not match the number of ranks")
+    if blocks[:2] != (1, 1) and not strong:
+        raise SystemExit("blocks in x / y are for strong scaling (weak scaling grows the box along z)")
+    # bounds of the ranks along every axis: weak = `lay` layers each along z (the box grows with the number of
+    # ranks), strong = the lattice cells of the one-GPU box split as evenly as possible
+    bounds = []
+    for ax in range(3):
+        p = blocks[ax]
+        if ax == 2 and not strong:
+            bounds.append(lay * np.arange(world + 1))
+        else:
+            bounds.append(np.array([(r * dims[ax]) // p for r in range(p + 1)]))
+        if np.any(np.diff(bounds[ax]) < 1):
+            raise SystemExit("more ranks than lattice layers")
+    bpos = (rank % blocks[0], (rank // blocks[0]) % blocks[1], rank // (blocks[0] * blocks[1]))
+    lo = [int(bounds[ax][bpos[ax]]) for ax in range(3)]
+    hi = [int(bounds[ax][bpos[ax] + 1]) for ax in range(3)]
+    o0 = [max(0, lo[ax] - 1) for ax in range(3)]            # local lattice range incl. the halo layers
+    o1 = [min(dims[ax], hi[ax] + 1) for ax in range(3)]
+    nl = [o1[ax] - o0[ax] for ax in range(3)]
+    g = pa.StructuredTetrahedralGrid(nl, [nl[0] / n, nl[1] / n, nl[2] / n])
     x = g.nodes.copy()
-    x[2] += k0 / n
+    for ax in range(3):
+        x[ax] += o0[ax] / n
     # global node id and perturbation of globally interior nodes
     nid = np.arange(g.num_nodes)
-    i, j, kl = nid % (n + 1), (nid // (n + 1)) % (n + 1), nid // ((n + 1) * (n + 1))
-    kg = kl + k0
-    ngid = i + (n + 1) * (j + (n + 1) * kg)
-    interior = (i > 0) & (i < n) & (j > 0) & (j < n) & (kg > 0) & (kg < ktot)
+    il = [nid % (nl[0] + 1), (nid // (nl[0] + 1)) % (nl[1] + 1), nid // ((nl[0] + 1) * (nl[1] + 1))]
+    ig = [il[ax] + o0[ax] for ax in range(3)]
+    ngid = ig[0] + (n + 1) * (ig[1] + (n + 1) * ig[2])
+    interior = np.ones(g.num_nodes, dtype=bool)
+    for ax in range(3):
+        interior &= (ig[ax] > 0) & (ig[ax] < dims[ax])
     amp = 0.2 / n
     for d in range(3):
         z = _hash_normal(ngid, 100 + 7 * d)
@@ -206,14 +249,16 @@ def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = N
     g.nodes = x
     g.compute_geometry()
     raw = pa.grid_to_raw(g)
-    # cells: local index -> (type, i, j, kl) -> global id, ownership
-    ncube = n * n * nl
+    # cells: local index -> (type, i, j, k) -> global id, ownership
+    ncube = nl[0] * nl[1] * nl[2]
     lc = np.arange(g.num_cells)
     t, cube = lc // ncube, lc % ncube
-    ci, cj, ckl = cube % n, (cube // n) % n, cube // (n * n)
-    ckg = ckl + k0
-    cgid = t + 6 * (ci + n * (cj + n * ckg))
-    owned = (ckg >= lo_k) & (ckg < hi_k)
+    cl = [cube % nl[0], (cube // nl[0]) % nl[1], cube // (nl[0] * nl[1])]
+    cg = [cl[ax] + o0[ax] for ax in range(3)]
+    cgid = t + 6 * (cg[0] + n * (cg[1] + n * cg[2]))
+    owned = np.ones(g.num_cells, dtype=bool)
+    for ax in range(3):
+        owned &= (cg[ax] >= lo[ax]) & (cg[ax] < hi[ax])
     # local numbering: owned cells first, each group along a Morton curve (locality of the SpMV gathers)
     io, ih = np.flatnonzero(owned), np.flatnonzero(~owned)
     box = (raw["face_centers"].min(axis=1), raw["face_centers"].max(axis=1))  # the library's quantisation box
@@ -221,18 +266,25 @@ def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = N
     ih = ih[D.morton_order(raw["cell_centers"][:, ih], 3, box)]
     order = np.concatenate([io, ih])
     raw = D.permute_cells(raw, order)
-    cgid, ckg = cgid[order], ckg[order]
+    cgid = cgid[order]
+    cg = [c[order] for c in cg]
     n_own = int(owned.sum())
-    # faces that are one-sided only because of the slab cut
-    fn_ptr, fn_idx = raw["fn_indptr"], raw["fn_indices"]
+    # faces that are one-sided only because of a cut
+    fn_idx = raw["fn_indices"]
     sides = np.bincount(raw["cf_indices"], minlength=g.num_faces)
-    fkl = kl[fn_idx].reshape(g.num_faces, 3)
-    on_bottom_cut = np.all(fkl == 0, axis=1) & (k0 > 0)
-    on_top_cut = np.all(fkl == nl, axis=1) & (k1 < ktot)
-    artificial = (sides == 1) & (on_bottom_cut | on_top_cut)
-    lp = D.LocalProblem(raw=raw, n_own=n_own, cell_gid=cgid.astype(np.int64),
-                        halo_owner=(np.searchsorted(bounds, ckg[n_own:], side="right") - 1).astype(np.int32), face_gid=None,
-                        artificial_boundary=artificial)
+    artificial = np.zeros(g.num_faces, dtype=bool)
+    for ax in range(3):
+        fl = il[ax][fn_idx].reshape(g.num_faces, 3)
+        artificial |= np.all(fl == 0, axis=1) & (o0[ax] > 0)
+        artificial |= np.all(fl == nl[ax], axis=1) & (o1[ax] < dims[ax])
+    artificial &= sides == 1
+    hown = np.zeros(g.num_cells - n_own, dtype=np.int64)
+    stride = 1
+    for ax in range(3):
+        hown += stride * (np.searchsorted(bounds[ax], cg[ax][n_own:], side="right") - 1)
+        stride *= blocks[ax]
+    lp = D.LocalProblem(raw=raw, n_own=n_own, cell_gid=cgid.astype(np.int64), halo_owner=hown.astype(np.int32),
+                        face_gid=None, artificial_boundary=artificial)
     # parameters: full-tensor anisotropic K times a log-normal field; Dirichlet p = x on x-faces
     scale = np.exp(0.5 * _hash_normal(cgid, 7))
     K = pa.SecondOrderTensor(kxx=1.0 * scale, kyy=10.0 * scale, kzz=0.1 * scale, kxy=0.5 * scale,
@@ -420,6 +472,9 @@ def main():
     ap.add_argument("--n-side", type=int, default=69, help="lattice cells per side (6 tets each)")
     ap.add_argument("--rtol", type=float, default=1e-13,
                     help="relative tolerance on the TRUE residual; 1e-13 is what 1e-10 field parity needs (SURVEY 8(d))")
+    ap.add_argument("--partition", choices=("auto", "slabs", "blocks"), default="auto",
+                    help="N > 1: how the box is cut -- z-slabs, or px x py x pz blocks as cubic as possible (2x2x2 at 8 "
+                         "ranks: 9 %% instead of 23 %% halo cells); auto = blocks for strong scaling, slabs for weak")
     ap.add_argument("--precond", choices=("amg", "amg_block", "jacobi"), default="amg",
                     help="preconditioner of the BiCGStab solve: aggregation-AMG cycle (default; N > 1: the coupled "
                          "hierarchy, halo exchange on every level), amg_block (N > 1 only: block Jacobi across ranks, "
@@ -474,7 +529,13 @@ def main():
 
     from porepy_amd import distributed as D
 
-    lp, Kvals, flags, bv, src, eta = make_slab_problem(args.n_side, rank, world, strong=args.scaling == "strong")
+    blocks = None  # z-slabs
+    if args.partition == "blocks" or (args.partition == "auto" and args.scaling == "strong"):
+        if args.scaling != "strong":
+            raise SystemExit("--partition blocks cuts the one-GPU box: it needs --scaling strong")
+        blocks = block_grid(world)
+    lp, Kvals, flags, bv, src, eta = make_slab_problem(args.n_side, rank, world, strong=args.scaling == "strong",
+                                                       blocks=blocks)
     nc = lp.n_own                      # cells this rank owns (halo cells are recomputed, not counted)
     nloc = lp.raw["cell_centers"].shape[1]
     if world == 1 and not args.force_sharded:
@@ -764,7 +825,8 @@ def main():
                        "global_cells": ncells_total,
                        "transport": (info.get("transport") if isinstance(info, dict) else None),
                        "parallelism": "1 GPU" if world == 1 else
-                       f"{world} z-slab subdomains (1 lattice layer of halo cells recomputed per cut), assembly "
+                       f"{world} subdomains ({'x'.join(str(p) for p in (blocks or (1, 1, world)))} blocks of the box, 1 lattice "
+                       "layer of halo cells recomputed per cut), assembly "
                        "without collectives, BiCGStab with RCCL point-to-point halo exchange + fused all-reduces; "
                        "AMG: per level and visit 2 point-to-point halo exchanges, one all-gather at the gathered level"},
             "roofline": roofline, "roofline_kernels": kernels[1:], "kernel_ms_per_step": per_step_ms,

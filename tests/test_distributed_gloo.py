@@ -185,7 +185,7 @@ def test_halo_plan_single_rank_is_noop():
     assert plan.bytes_per_exchange == 0
 
 
-def _slab_worker(rank, world, port, out, strong=False):
+def _slab_worker(rank, world, port, out, strong=False, blocks=None):
     import torch
     import torch.distributed as dist
 
@@ -196,32 +196,38 @@ def _slab_worker(rank, world, port, out, strong=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lib = P.emulation_library()
-        if strong:  # the 7-layer one-rank box split 2 + 2 + 3
+        if blocks:  # the one-rank box cut in blocks (3 + 4 lattice cells along the cut axes)
+            lp, Kv, flags, bv, src, eta = bench.make_slab_problem(7, rank, world, strong=True, blocks=blocks)
+        elif strong:  # the 7-layer one-rank box split 2 + 2 + 3
             lp, Kv, flags, bv, src, eta = bench.make_slab_problem(7, rank, world, strong=True)
         else:
             lp, Kv, flags, bv, src, eta = bench.make_slab_problem(4, rank, world, layers=3)
         sh = D.ShardedMpfa(lp, device="cpu", library=lib, dist=dist)
         sh.discretize(Kv, flags, None, eta)
         sh.assemble(bv, src)
-        x, info = sh.solve("bicgstab", rtol=1e-12, maxit=3000, check_every=1)
-        torch.save({"gid": lp.cell_gid[: lp.n_own], "x": x.numpy(), "info": info}, os.path.join(out, f"s{rank}.pt"))
+        x, info = sh.solve("bicgstab", rtol=1e-12, maxit=3000, check_every=1, precond="amg" if blocks else "jacobi")
+        torch.save({"gid": lp.cell_gid[: lp.n_own], "x": x.numpy(), "info": info, "peers": sorted(sh.plan.send_cells)},
+                   os.path.join(out, f"s{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("strong", [False, True])
+@pytest.mark.parametrize("strong", [False, True, (1, 2, 2)], ids=["weak-slabs", "strong-slabs", "strong-blocks-1x2x2"])
 def test_bench_slab_decomposition_matches_single_domain(tmp_path, strong):
     """The slab problems bench.py builds per rank (no global grid) are one global problem:
     3 ranks x 3 lattice layers reproduce the 9-layer single-domain solution (weak scaling); the
-    7-layer box of one rank split 2 + 2 + 3 reproduces itself (--scaling strong)."""
+    7-layer box of one rank split 2 + 2 + 3 reproduces itself (--scaling strong); so does the box cut into 1 x 2 x 2
+    blocks (--partition blocks: every rank then has edge and corner neighbours too, solved with the coupled
+    hierarchy)."""
     import torch
     import torch.multiprocessing as mp
 
     import bench
 
-    world = 3
+    blocks = strong if isinstance(strong, tuple) else None
+    world = 4 if blocks else 3
     P.emulation_library()  # build once here, not concurrently in the workers
-    mp.spawn(_slab_worker, args=(world, _free_port(), str(tmp_path), strong), nprocs=world, join=True)
+    mp.spawn(_slab_worker, args=(world, _free_port(), str(tmp_path), bool(strong), blocks), nprocs=world, join=True)
     lib = P.emulation_library()
     if strong:
         lp, Kv, flags, bv, src, eta = bench.make_slab_problem(7, 0, 1, strong=True)
@@ -240,6 +246,8 @@ def test_bench_slab_decomposition_matches_single_domain(tmp_path, strong):
     for r in range(world):
         o = torch.load(os.path.join(str(tmp_path), f"s{r}.pt"), weights_only=False)
         assert o["info"]["converged"]
+        if blocks:
+            assert len(o["peers"]) == 3  # face neighbour in y, in z, and the block across the edge
         want = np.array([ref_by_gid[g] for g in o["gid"].tolist()])
         assert np.linalg.norm(o["x"] - want) <= 1e-9 * np.linalg.norm(x_ref)
         total += o["gid"].size
