@@ -351,7 +351,11 @@ class RcclComm:
 
     def close(self):
         if getattr(self, "_c", None) is not None and self._c:
-            self.lib.pfv_rccl_comm_destroy(self._c)
+            # The communicator lives on its handle's stream and memory pool.  When both die in one garbage cycle the
+            # handle's finalizer may already have run (weak references are cleared before finalizers, so the handle
+            # could not close this object first): its memory went with the handle, nothing is left to destroy.
+            if getattr(self.ctx, "_h", None):
+                self.lib.pfv_rccl_comm_destroy(self._c)
             self._c = C.c_void_p()
 
     def __del__(self):

@@ -329,10 +329,15 @@ class ShardedMpfa:
         world = dist.get_world_size() if dist is not None else 1
         stage = self.device.type == "cuda" and dist is not None and dist.get_backend() == "gloo"
         failure = self._hook_failures = []
+        import weakref
+
+        me = weakref.ref(self)  # (the callbacks are stored on the handle this object owns: no reference cycle through them)
+        device = self.device
 
         def sendrecv(_user, n_peers, peers, d_send, send_ptr, d_recv, recv_ptr, _stream):
             try:
-                if self.device.type == "cuda":
+                self = me()
+                if device.type == "cuda":
                     self.ctx.sync()
                 ops, landing = [], []
                 for i in range(n_peers):
@@ -351,8 +356,8 @@ class ShardedMpfa:
                 for rb, buf in landing:
                     if buf is not rb:
                         rb.copy_(buf)
-                if self.device.type == "cuda":
-                    torch.cuda.synchronize(self.device)
+                if device.type == "cuda":
+                    torch.cuda.synchronize(device)
                 return 0
             except BaseException as e:  # must not propagate through the C frames
                 failure.append(e)
@@ -360,7 +365,8 @@ class ShardedMpfa:
 
         def allgather(_user, d_send, d_recv, nbytes, _stream):
             try:
-                if self.device.type == "cuda":
+                self = me()
+                if device.type == "cuda":
                     self.ctx.sync()
                 src = self._view(int(d_send), nbytes)
                 dst = self._view(int(d_recv), nbytes * world)
@@ -372,8 +378,8 @@ class ShardedMpfa:
                     dst.copy_(torch.cat(parts))
                 else:
                     dist.all_gather(list(dst.chunk(world)), src)
-                if self.device.type == "cuda":
-                    torch.cuda.synchronize(self.device)
+                if device.type == "cuda":
+                    torch.cuda.synchronize(device)
                 return 0
             except BaseException as e:
                 failure.append(e)

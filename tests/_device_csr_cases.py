@@ -119,6 +119,16 @@ def input_checks(lib):
     with pytest.raises(pa.PorefvError, match="zero diagonal"):
         pa.DeviceCsr.from_scipy(sps.csr_matrix(np.array([[0.0, 1.0], [1.0, 1.0]])), ctx).as_system(np.ones(2))
     ctx.close()
+    # a matrix and its handle dying in one garbage cycle: whichever finalizer runs first, nothing is freed twice and
+    # nothing is freed through a dead handle (weak references are cleared before finalizers run)
+    import gc
+
+    for _ in range(3):
+        c2 = pa.Context(0, lib)
+        m2 = pa.DeviceCsr.from_scipy(A, c2)
+        c2.keeps = m2  # cycle: matrix -> handle -> matrix
+        del c2, m2
+        gc.collect()
 
 
 def discretization_to_system(lib):
