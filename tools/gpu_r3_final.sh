@@ -18,6 +18,12 @@ bash tools/gpu_r3_trace.sh $1 final: > $O/trace_console.log 2>&1
 stamp trace
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 stamp bench_default
+# device fuzz against PorePy itself (byte-compiled archive): plain cases, then the special ones (conditions per sub-face,
+# partial discretization, tilted 2-D grids, TPFA, continuity points per sub-face)
+(cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=$R/oracle/shim:$R/oracle/_ref/porepy_ref.zip:$R timeout 400 python $R/tools/fuzz_vs_reference.py 40 11000 > $R/$O/fuzz_device_vs_reference.log 2>&1)
+(cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=$R/oracle/shim:$R/oracle/_ref/porepy_ref.zip:$R timeout 400 python $R/tools/fuzz_vs_reference.py 30 12000 special > $R/$O/fuzz_device_vs_reference_special.log 2>&1)
+tail -2 $O/fuzz_device_vs_reference.log $O/fuzz_device_vs_reference_special.log
+stamp fuzz
 python - "$O" <<'PY'
 import json, sys
 o = sys.argv[1]
