@@ -22,7 +22,7 @@ stamp bench_default
 # partial discretization, tilted 2-D grids, TPFA, continuity points per sub-face)
 (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=$R/oracle/shim:$R/oracle/_ref/porepy_ref.zip:$R timeout 400 python $R/tools/fuzz_vs_reference.py 40 11000 > $R/$O/fuzz_device_vs_reference.log 2>&1)
 (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=$R/oracle/shim:$R/oracle/_ref/porepy_ref.zip:$R timeout 400 python $R/tools/fuzz_vs_reference.py 30 12000 special > $R/$O/fuzz_device_vs_reference_special.log 2>&1)
-tail -2 $O/fuzz_device_vs_reference.log $O/fuzz_device_vs_reference_special.log
+tail -n 2 $O/fuzz_device_vs_reference.log; tail -n 2 $O/fuzz_device_vs_reference_special.log
 stamp fuzz
 python - "$O" <<'PY'
 import json, sys
