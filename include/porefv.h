@@ -477,6 +477,10 @@ pfv_status pfv_csr_block_diag(pfv_ctx* h, int n, const pfv_csr* const* blocks, p
 pfv_status pfv_csr_matmul(pfv_ctx* h, const pfv_csr* A, const pfv_csr* B, pfv_csr** out);   /* A B; PFV_ERR_UNSUPPORTED
                                                                      when more than 4096 products feed one row */
 pfv_status pfv_csr_axpby(pfv_ctx* h, double alpha, const pfv_csr* A, double beta, const pfv_csr* B, pfv_csr** out);
+pfv_status pfv_csr_transpose(pfv_ctx* h, const pfv_csr* A, pfv_csr** out);
+/* scipy.sparse.bmat: nbr x nbc blocks, row-major, NULL = zero block of row_sizes[i] x col_sizes[j] */
+pfv_status pfv_csr_bmat(pfv_ctx* h, int nbr, int nbc, const pfv_csr* const* blocks, const int64_t* row_sizes,
+                        const int64_t* col_sizes, pfv_csr** out);
 pfv_status pfv_csr_scale(pfv_csr* A, const double* row_scale, const double* col_scale);   /* in place; host arrays or NULL */
 pfv_status pfv_csr_spmv(const pfv_csr* A, const double* x, double* y);                     /* host vectors */
 pfv_status pfv_csr_spmv_device(const pfv_csr* A, const double* d_x, double* d_y);

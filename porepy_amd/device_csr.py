@@ -122,6 +122,13 @@ class DeviceCsr:
     def __sub__(self, other):
         return self.axpby(1.0, other, -1.0)
 
+    @property
+    def T(self) -> "DeviceCsr":
+        """The transpose (rows sorted: what ``A.T.tocsr()`` gives in scipy)."""
+        return self._binary(self.ctx.lib.pfv_csr_transpose, self._c)
+
+    transpose = lambda self: self.T  # noqa: E731
+
     def copy(self) -> "DeviceCsr":
         return self.scaled()
 
@@ -204,6 +211,36 @@ def block_diag(mats, context: "_lib.Context | None" = None) -> DeviceCsr:
     arr = (_lib._h * max(len(dm), 1))(*[m._c for m in dm])
     out = _lib._h()
     context._check(context.lib.pfv_csr_block_diag(context._h, len(dm), arr, C.byref(out)))
+    return DeviceCsr(context, out)
+
+
+def bmat(blocks, context: "_lib.Context | None" = None) -> DeviceCsr:
+    """``scipy.sparse.bmat`` on the device: a block matrix from a grid (list of rows) of blocks, ``None`` = zero block.
+    Stacking the equations of several variables -- the last step of ``EquationSystem.assemble`` -- without the pieces
+    leaving HBM.  Every block row and every block column needs at least one block to take its size from."""
+    rows = [list(r) for r in blocks]
+    nbr, nbc = len(rows), len(rows[0])
+    if any(len(r) != nbc for r in rows):
+        raise ValueError("ragged block grid")
+    if context is None:
+        context = next((m.ctx for r in rows for m in r if isinstance(m, DeviceCsr)), None)
+        if context is None:
+            raise ValueError("bmat of host matrices needs a context")
+    dm = [[None if m is None else DeviceCsr.from_any(m, context) for m in r] for r in rows]
+    rs, cs = [None] * nbr, [None] * nbc
+    for i in range(nbr):
+        for j in range(nbc):
+            if dm[i][j] is not None:
+                sh = dm[i][j].shape
+                rs[i] = sh[0] if rs[i] is None else rs[i]
+                cs[j] = sh[1] if cs[j] is None else cs[j]
+    if any(v is None for v in rs + cs):
+        raise ValueError("a block row or column without any block: its size is unknown")
+    arr = (_lib._h * (nbr * nbc))(*[(m._c if m is not None else None) for r in dm for m in r])
+    rsa, csa = np.asarray(rs, dtype=np.int64), np.asarray(cs, dtype=np.int64)
+    out = _lib._h()
+    context._check(context.lib.pfv_csr_bmat(context._h, nbr, nbc, arr, _lib._ptr(rsa, _lib._lp), _lib._ptr(csa, _lib._lp),
+                                            C.byref(out)))
     return DeviceCsr(context, out)
 
 

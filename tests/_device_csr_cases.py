@@ -69,6 +69,12 @@ def random_algebra(lib):
         r, c = rng.random(m) + 0.5, rng.random(k) + 0.5
         same(dA.scaled(r, c).to_scipy(), sps.diags(r) @ A @ sps.diags(c))
         same(pa.block_diag([dA, dB, dC]).to_scipy(), sps.block_diag([A, B, C], format="csr"))
+        same(dA.T.to_scipy(), A.T.tocsr())
+        same((dA.T @ dC).to_scipy(), A.T.tocsr() @ C)
+        same(pa.bmat([[dA, None, dC], [None, dB.T, None]]).to_scipy(),
+             sps.bmat([[A, None, C], [None, B.T, None]], format="csr"))
+        same(pa.bmat([[dA], [dC]]).to_scipy(), sps.vstack([A, C], format="csr"))
+        same(pa.bmat([[dA, dC]]).to_scipy(), sps.hstack([A, C], format="csr"))
         x = rng.random(k)
         assert np.allclose(dA @ x, A @ x, rtol=0, atol=1e-14 * max(1.0, abs(A).sum(axis=1).max()))
         # a chain as the operator tree builds it: (A B) D + E
@@ -116,6 +122,10 @@ def input_checks(lib):
     wide = sps.csr_matrix(np.ones((70, 70)))
     with pytest.raises(pa.PorefvError, match="4096"):
         pa.DeviceCsr.from_scipy(big, ctx) @ pa.DeviceCsr.from_scipy(wide, ctx)
+    with pytest.raises(pa.PorefvError, match="does not fit"):
+        pa.bmat([[dA, dA], [pa.DeviceCsr.from_scipy(sps.random(19, 20, 0.3, random_state=1, format="csr"), ctx), dA]])
+    with pytest.raises(ValueError, match="size is unknown"):
+        pa.bmat([[dA, None], [dA, None]])
     with pytest.raises(pa.PorefvError, match="zero diagonal"):
         pa.DeviceCsr.from_scipy(sps.csr_matrix(np.array([[0.0, 1.0], [1.0, 1.0]])), ctx).as_system(np.ones(2))
     ctx.close()
@@ -189,6 +199,24 @@ def merged_subdomains(lib):
     inner = bf @ proj_h
     inner.sort_indices()
     same((div @ (bound_flux @ proj)).to_scipy(), div_h @ inner)
+    # ... and stacked with a second equation into one block system, as EquationSystem.assemble stacks the equations of
+    # its variables: [[Div Flux, Div BoundFlux P], [P^T BoundPressureCell, P^T BoundPressureFace P + I]]
+    bpc = pa.merged_matrix([d3, d2], "flow", "bound_pressure_cell", ctx)
+    bpf = pa.merged_matrix([d3, d2], "flow", "bound_pressure_face", ctx)
+    eye = pa.DeviceCsr.from_scipy(sps.identity(11, format="csr"), ctx)
+    J = pa.bmat([[div @ flux, div @ (bound_flux @ proj)], [proj.T @ bpc, (proj.T @ (bpf @ proj)) + eye]])
+
+    def canon(m):
+        m = sps.csr_matrix(m)
+        m.sort_indices()
+        return m
+
+    projT = canon(proj_h.T)
+    J_h = sps.bmat([[div_h @ fl, div_h @ inner],
+                    [projT @ bpc.to_scipy(), canon(projT @ canon(bpf.to_scipy() @ proj_h)) + sps.identity(11, format="csr")]],
+                   format="csr")
+    same(J.to_scipy(), J_h)
+    assert J.shape == (g3.num_cells + g2.num_cells + 11,) * 2
     p = rng.random(g3.num_cells + g2.num_cells)
     lam = rng.random(11)
     q = flux @ p + bound_flux @ (proj @ lam)
