@@ -7,6 +7,7 @@ O=gpurun_out/$1
 mkdir -p $O
 t0=$(date +%s)
 stamp() { echo "[$(( $(date +%s) - t0 )) s] $*" >> $O/timeline.log; }
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -n 1 $O/smoke.log
 timeout 1200 python -m pytest tests -m gpu -q --timeout 400 --durations=10 > $O/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log; stamp tests
 # PMC passes (counters apart from the kernel trace)
