@@ -87,6 +87,8 @@ struct pfv_ctx_impl {
   int device = 0;
   stream_t stream{};      // stream all work of this handle is issued on
   stream_t own_stream{};  // the stream created with the handle (stream may point elsewhere, pfv_set_stream)
+  Buf<double> sys_rowmax;            // largest off-diagonal |a_ij| of every row of A, left by assemble_system
+  const double* sys_rowmax_for = nullptr;  // ... for this value array (nullptr: none)
   stream_t aux_stream{};  // second stream of the handle: the interaction-region kernel runs there while the
                           // symbolic phase runs on `stream` (both only need the sub-cell topology)
   std::string err;
