@@ -23,10 +23,18 @@ _METHODS = {"hip_bicgstab": "bicgstab", "hip_gmres": "gmres", "hip_cg": "cg"}
 
 def solve_csr(A, b, method: str = "bicgstab", rtol: float = 1e-12, maxit: int = 50000, restart: int = 0,
               device: int = 0, library=None, context: _lib.Context | None = None, precond: str = "jacobi", x0=None):
-    """x with ||b - A x|| <= rtol ||b||, computed on the device; returns (x, info).  ``context``: a handle to reuse
-    (its buffers, streams and memory pool) instead of a fresh one per call; ``x0``: initial guess."""
-    ctx = context if context is not None else _lib.Context(device, library)
-    ctx.set_system(A, b)
+    """x with ||b - A x|| <= rtol ||b||, computed on the device; returns (x, info).  ``A``: scipy sparse, or a
+    ``DeviceCsr`` (solved where it lives).  ``context``: a handle to reuse (its buffers, streams and memory pool)
+    instead of a fresh one per call; ``x0``: initial guess."""
+    from .device_csr import DeviceCsr
+
+    if isinstance(A, DeviceCsr):
+        # a system assembled on the device (device_csr.py): it becomes the active system of the solving handle without
+        # a host copy (pfv_csr_set_system)
+        ctx = A.as_system(b, context=context)
+    else:
+        ctx = context if context is not None else _lib.Context(device, library)
+        ctx.set_system(A, b)
     return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, restart=restart, n=A.shape[0], precond=precond)
 
 

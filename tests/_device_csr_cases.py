@@ -168,6 +168,9 @@ def discretization_to_system(lib):
     x, info = solver.solve("bicgstab", rtol=1e-12, maxit=2000, n=g.num_cells, precond="amg")
     x_ref = spla.spsolve(A_ref.tocsc(), b_ref)
     assert np.linalg.norm(x - x_ref) <= 1e-9 * np.linalg.norm(x_ref)
+    # the same through the solver entry point of the host mirror
+    x2, info2 = pa.solve_csr(J, rhs, rtol=1e-12, precond="amg")
+    assert info2["converged"] and np.linalg.norm(x2 - x_ref) <= 1e-9 * np.linalg.norm(x_ref)
 
 
 def merged_subdomains(lib):
