@@ -474,8 +474,8 @@ pfv_status pfv_csr_from_host(pfv_ctx* h, int64_t nrows, int64_t ncols, const int
 /* device-to-device copy of matrix `which` (pfv_matrix_id) of handle src */
 pfv_status pfv_csr_from_matrix(pfv_ctx* h, pfv_ctx* src, int which, pfv_csr** out);
 pfv_status pfv_csr_block_diag(pfv_ctx* h, int n, const pfv_csr* const* blocks, pfv_csr** out);
-pfv_status pfv_csr_matmul(pfv_ctx* h, const pfv_csr* A, const pfv_csr* B, pfv_csr** out);   /* A B; PFV_ERR_UNSUPPORTED
-                                                                     when more than 4096 products feed one row */
+pfv_status pfv_csr_matmul(pfv_ctx* h, const pfv_csr* A, const pfv_csr* B, pfv_csr** out);   /* A B (rows fed by more than
+                                                     4096 products take a slower path through global sorts) */
 pfv_status pfv_csr_axpby(pfv_ctx* h, double alpha, const pfv_csr* A, double beta, const pfv_csr* B, pfv_csr** out);
 pfv_status pfv_csr_transpose(pfv_ctx* h, const pfv_csr* A, pfv_csr** out);
 /* scipy.sparse.bmat: nbr x nbc blocks, row-major, NULL = zero block of row_sizes[i] x col_sizes[j] */

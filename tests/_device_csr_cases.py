@@ -1,6 +1,8 @@
 """Cases of the device-resident CSR algebra (DeviceCsr, csrc/csr_algebra.inc), shared by the CPU suite (host-emulation
 library) and the GPU suite (gfx950 library): every result is compared with scipy's on the same inputs -- bit for bit
 where scipy computes the same thing (products, sums, block diagonals follow its accumulation order)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sps
@@ -117,11 +119,20 @@ def input_checks(lib):
         dA @ pa.DeviceCsr.from_scipy(sps.random(19, 4, 0.3, random_state=1, format="csr"), ctx)
     with pytest.raises(pa.PorefvError, match="shapes differ"):
         dA + pa.DeviceCsr.from_scipy(sps.random(20, 19, 0.3, random_state=1, format="csr"), ctx)
-    # more products per row than the LDS sort holds: a refusal, not a wrong result
-    big = sps.csr_matrix(np.ones((1, 70)))
-    wide = sps.csr_matrix(np.ones((70, 70)))
-    with pytest.raises(pa.PorefvError, match="4096"):
-        pa.DeviceCsr.from_scipy(big, ctx) @ pa.DeviceCsr.from_scipy(wide, ctx)
+    # more products per row than the LDS sort holds: the path through global sorts, same bits
+    rng = np.random.default_rng(3)
+    big = sps.csr_matrix(rng.random((3, 70)) - 0.5)
+    wide = sps.csr_matrix(rng.random((70, 70)) - 0.5)
+    same((pa.DeviceCsr.from_scipy(big, ctx) @ pa.DeviceCsr.from_scipy(wide, ctx)).to_scipy(), big @ wide)
+    os.environ["PFV_SPGEMM_GENERIC"] = "1"   # ... which any product can be sent through
+    try:
+        for seed in range(4):
+            M1 = sps.random(40, 30, 0.2, random_state=seed, format="csr")
+            M2 = sps.random(30, 50, 0.2, random_state=seed + 10, format="csr")
+            M2 = sps.csr_matrix(M2 - M2.multiply(M2 > 0.8))  # (some exact cancellations)
+            same((pa.DeviceCsr.from_scipy(M1, ctx) @ pa.DeviceCsr.from_scipy(M2, ctx)).to_scipy(), M1 @ M2)
+    finally:
+        del os.environ["PFV_SPGEMM_GENERIC"]
     with pytest.raises(pa.PorefvError, match="does not fit"):
         pa.bmat([[dA, dA], [pa.DeviceCsr.from_scipy(sps.random(19, 20, 0.3, random_state=1, format="csr"), ctx), dA]])
     with pytest.raises(ValueError, match="size is unknown"):
