@@ -660,6 +660,7 @@ class ShardedMpfa:
             self.ctx.sync()
             info["halo_bytes_per_exchange"] = self.plan.bytes_per_exchange
             info["driver"] = "library"
+            info["hierarchy"] = want
             info["transport"] = "rccl (native hooks)"
             return x, info
         self._use_torch_stream()
@@ -688,10 +689,17 @@ class ShardedMpfa:
                 else:
                     self.dist.all_reduce(red)
 
-        info = self.ctx.solve_sharded(n, exchange_halo, allreduce_sum, work.data_ptr(), x.data_ptr(),
-                                      method=method, rtol=rtol, maxit=maxit, precond=precond)
+        try:
+            info = self.ctx.solve_sharded(n, exchange_halo, allreduce_sum, work.data_ptr(), x.data_ptr(),
+                                          method=method, rtol=rtol, maxit=maxit, precond=precond)
+        except _lib.PorefvError as e:
+            # a transport callback of the coupled hierarchy failed inside the cycle: its own exception says why
+            if getattr(self, "_hook_failures", None):
+                raise self._hook_failures[0] from e
+            raise
         info["halo_bytes_per_exchange"] = self.plan.bytes_per_exchange
         info["driver"] = "library"
+        info["hierarchy"] = want
         info["transport"] = "torch.distributed hooks"
         return x, info
 
