@@ -413,11 +413,14 @@ class ShardedMpfa:
             hooks = self._torch_transport()
         peers = sorted(set(self.plan.send_cells) | set(self.plan.recv_cells))
         empty = np.zeros(0, dtype=np.int32)
-        self.ctx.amg_setup_sharded(self.n_own, hooks, rank, world, peers,
-                                   [self.plan.send_cells.get(p, empty) for p in peers],
-                                   [self.plan.recv_cells.get(p, empty) for p in peers])
-        if getattr(self, "_hook_failures", None):
-            raise self._hook_failures[0]
+        try:
+            self.ctx.amg_setup_sharded(self.n_own, hooks, rank, world, peers,
+                                       [self.plan.send_cells.get(p, empty) for p in peers],
+                                       [self.plan.recv_cells.get(p, empty) for p in peers])
+        except _lib.PorefvError as e:
+            if native is None and getattr(self, "_hook_failures", None):
+                raise self._hook_failures[0] from e  # the transport callback's own exception says why
+            raise
         self._amg_ready = "coupled-native" if native is not None else "coupled"
 
     def _spmv_owned(self, x_full, out_owned):

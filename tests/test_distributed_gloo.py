@@ -176,6 +176,50 @@ def test_hook_failure_aborts_the_sharded_solve():
     assert info2["converged"] and np.array_equal(x.numpy(), x2.numpy())
 
 
+def test_transport_failure_inside_the_coupled_hierarchy_is_reported(monkeypatch):
+    """The transport of the coupled hierarchy (sendrecv / allgather of pfv_shard_hooks) fails: in the setup the
+    library reports it (status 4) and the Python side re-raises the callback's own exception; in the cycle the solve
+    stops and does the same; afterwards the handle still solves."""
+    lib = P.emulation_library()
+    g, K, bc, bv, src = _problem("tet")
+    raw = pa.grid_to_raw(g)
+    lp = D.extract_subdomain(raw, np.zeros(g.num_cells, dtype=np.int32), 0)
+    sh = D.ShardedMpfa(lp, device="cpu", library=lib, dist=None)
+    sh.discretize(K.values[:, :, lp.cell_gid], sh.local_bc_flags(pa.bc_flags(bc)[lp.face_gid]),
+                  bc.robin_weight[lp.face_gid], pa.determine_eta(g))
+    sh.assemble(bv[lp.face_gid], src[lp.cell_gid])
+    x, info = sh.solve("bicgstab", rtol=1e-10, precond="amg")
+    assert info["converged"] and info["hierarchy"] == "coupled"
+
+    class Boom(RuntimeError):
+        pass
+
+    calls = {"n": 0, "fail_from": 0}
+    real_view = sh._view
+
+    def flaky_view(ptr, nbytes):  # every transport callback goes through _view
+        calls["n"] += 1
+        if calls["n"] > calls["fail_from"]:
+            raise Boom("link down")
+        return real_view(ptr, nbytes)
+
+    monkeypatch.setattr(sh, "_view", flaky_view)
+    sh._system_changed()  # the hierarchy is set up again by the next solve
+    with pytest.raises(Boom):  # ... and its first allgather fails
+        sh.solve("bicgstab", rtol=1e-10, precond="amg")
+    # failure inside the cycle: the setup of this system needs a fixed number of transport calls, the next one fails
+    calls.update(n=0, fail_from=10 ** 9)
+    sh._system_changed()
+    sh.amg_setup(coupled=True)
+    calls.update(fail_from=calls["n"])
+    with pytest.raises(Boom):
+        sh.solve("bicgstab", rtol=1e-10, precond="amg")
+    monkeypatch.undo()
+    sh._system_changed()
+    x2, info2 = sh.solve("bicgstab", rtol=1e-10, precond="amg")
+    assert info2["converged"] and np.array_equal(x.numpy(), x2.numpy())
+
+
 def test_halo_plan_single_rank_is_noop():
     g, K, bc, bv, src = _problem("cart")
     raw = pa.grid_to_raw(g)
