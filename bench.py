@@ -644,9 +644,12 @@ def main():
     kernels = []
     spmv_ms = ctx.time_kernel(0, reps=50)
     spmv_bytes = 12.0 * nnzA + 4.0 * (nloc + 1) + 8.0 * nloc + 8.0 * nloc  # values+indices, indptr, x, y
+    # launches per step: two products per BiCGStab iteration + the product of the true-residual check that ends every
+    # solve (linalg.inc: krylov_solve, PFV_TRUE_RESIDUAL) -- the same kernel on the same matrix
+    true_residual_products = 0 if (sh is not None or os.environ.get("PFV_TRUE_RESIDUAL", "1") == "0") else 1
     kernels.append(hbm_entry(
         "krylov_f64_product", "k_spmv_win<double> (CSR SpMV with A in f64, x window staged in LDS, fused dots)",
-        spmv_bytes, spmv_ms, 2 * its,
+        spmv_bytes, spmv_ms, 2 * its + true_residual_products,
         "achieved = SURVEY 8(d) CSR bytes (12 B per entry) / time; the kernel itself streams ~10 B per entry "
         "(16-bit window-local column indices)", "krylov",
         {"streamed_GBs": (10.0 * nnzA + 4.0 * (nloc + 1) + 8.0 * nloc + 12.0 * nloc * 0.36) / (spmv_ms * 1e-3) / 1e9}))
