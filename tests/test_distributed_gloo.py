@@ -529,3 +529,31 @@ def test_sharded_thermo_hydro_mixed_dimensional_jacobian(tmp_path):
     xo = spla2.spsolve(A.tocsc(), z["b"])
     assert np.linalg.norm(xo - z["x"]) <= 1e-9 * np.linalg.norm(xo)  # the fixture's known answer
     assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+
+
+def test_block_partition_covers_the_box_once():
+    """bench.py's strong-scaling cut (`block_grid`, `make_slab_problem(blocks=...)`): the block grids are as cubic as
+    possible, every lattice cell is owned by exactly one rank, halo cells name their owners, and 2 x 2 x 2 blocks carry
+    fewer halo cells than eight slabs."""
+    import bench
+
+    assert [bench.block_grid(w) for w in (1, 2, 3, 4, 6, 8, 12, 16)] == [
+        (1, 1, 1), (1, 1, 2), (1, 1, 3), (1, 2, 2), (1, 2, 3), (2, 2, 2), (2, 2, 3), (2, 2, 4)]
+    n = 8
+    halo = {}
+    for blocks in ((2, 2, 2), (1, 1, 8)):
+        owned, frac = [], []
+        gid_of_rank = {}
+        for r in range(8):
+            lp, *_ = bench.make_slab_problem(n, r, 8, strong=True, blocks=blocks)
+            owned.append(lp.cell_gid[: lp.n_own])
+            gid_of_rank[r] = set(lp.cell_gid[: lp.n_own].tolist())
+            frac.append((lp.cell_gid.size - lp.n_own) / lp.n_own)
+        allg = np.concatenate(owned)
+        assert allg.size == 6 * n ** 3 and np.unique(allg).size == allg.size
+        halo[blocks] = float(np.mean(frac))
+        # the owner recorded for every halo cell of rank 0 does own it
+        lp, *_ = bench.make_slab_problem(n, 0, 8, strong=True, blocks=blocks)
+        for g, q in zip(lp.cell_gid[lp.n_own:].tolist(), lp.halo_owner.tolist()):
+            assert g in gid_of_rank[q]
+    assert halo[(2, 2, 2)] < 0.6 * halo[(1, 1, 8)]
