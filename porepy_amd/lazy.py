@@ -21,13 +21,14 @@ import numpy as np
 class LazyCsr:
     __array_priority__ = 20.0  # numpy defers to our __rmatmul__ / __rmul__
 
-    def __init__(self, ctx, which: int, post=None):
+    def __init__(self, ctx, which: int, post=None, shape=None):
         self._ctx = ctx
         self._which = int(which)
         self._post = post          # optional host-side post-processing of the fetched matrix
         self._m = None
         nrows, ncols, nnz = ctx.matrix_info(which)
-        self._shape = (int(nrows), int(ncols))
+        # (shape: what the post-processing turns the matrix into, when it changes it)
+        self._shape = (int(nrows), int(ncols)) if shape is None else (int(shape[0]), int(shape[1]))
         self._nnz = int(nnz)
         ctx._lazy_refs.append(weakref.ref(self))
 

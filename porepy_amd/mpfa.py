@@ -489,10 +489,22 @@ class Mpfa:
 
             basis = T if T is not None else np.eye(2, 3)
             lift = sps.kron(sps.identity(sd.num_cells, format="csr"), sps.csr_matrix(basis), format="csr")
-        simple = merge is None and lift is None and order is None and rows is None and not (partial and update)
+        simple = merge is None and order is None and rows is None and not (partial and update)
+
+        def lifted(m, L=lift):
+            m = (m @ L).tocsr()
+            m.sort_indices()
+            return m
+
         for name, which in _KEYS:
             if self.lazy and simple:
-                md[name] = LazyCsr(ctx, which)
+                # (a tilted 2-D grid: only the vector-source matrices need the lift -- applied when one of them is
+                # fetched; flux, bound_flux and the pressure traces stay plain device-resident proxies)
+                if lift is not None and "vector_source" in name:
+                    nr, _, _ = ctx.matrix_info(which)
+                    md[name] = LazyCsr(ctx, which, post=lifted, shape=(nr, lift.shape[1]))
+                else:
+                    md[name] = LazyCsr(ctx, which)
                 continue
             new = ctx.matrix(which, rows=rows)
             if merge is not None:
