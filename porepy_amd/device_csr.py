@@ -68,8 +68,12 @@ class DeviceCsr:
 
         if isinstance(m, DeviceCsr):
             return m
-        if isinstance(m, LazyCsr) and not m.materialized and m._post is None and m._ctx is not None:
-            return cls.from_discretization(m._ctx, m._which, context)
+        if isinstance(m, LazyCsr) and not m.materialized and m._ctx is not None:
+            if m._post is None:
+                return cls.from_discretization(m._ctx, m._which, context)
+            if getattr(m, "_right", None) is not None:
+                # (the lift of a fracture plane's vector-source columns into the ambient space: a product on the device)
+                return cls.from_discretization(m._ctx, m._which, context) @ cls.from_scipy(m._right, context)
         return cls.from_scipy(m.tocsr() if isinstance(m, LazyCsr) else m, context)
 
     # ---- facts -------------------------------------------------------------------------------------------------

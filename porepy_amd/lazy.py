@@ -21,7 +21,10 @@ import numpy as np
 class LazyCsr:
     __array_priority__ = 20.0  # numpy defers to our __rmatmul__ / __rmul__
 
-    def __init__(self, ctx, which: int, post=None, shape=None):
+    def __init__(self, ctx, which: int, post=None, shape=None, right=None):
+        # right: when the post-processing is a product with a (small) sparse matrix from the right, that matrix -- a
+        # device-side consumer (device_csr.DeviceCsr.from_any) then forms the product on the device instead of fetching
+        self._right = right
         self._ctx = ctx
         self._which = int(which)
         self._post = post          # optional host-side post-processing of the fetched matrix

@@ -502,7 +502,7 @@ class Mpfa:
                 # fetched; flux, bound_flux and the pressure traces stay plain device-resident proxies)
                 if lift is not None and "vector_source" in name:
                     nr, _, _ = ctx.matrix_info(which)
-                    md[name] = LazyCsr(ctx, which, post=lifted, shape=(nr, lift.shape[1]))
+                    md[name] = LazyCsr(ctx, which, post=lifted, shape=(nr, lift.shape[1]), right=lift)
                 else:
                     md[name] = LazyCsr(ctx, which)
                 continue

@@ -121,10 +121,9 @@ def test_merged_operator_parse_and_flux_products_on_the_device(variant):
     assert out["subdomains"] == 4 and out["dims"] == [3, 2, 1]
     assert out["block_diag_bit_identical_to_reference_parse"] is True
     assert all(v == "device" for v in out["where_the_blocks_were"]["dim3"].values())
-    # the fracture planes (2-D grids embedded in 3-D): everything but the vector-source matrices, which carry the
-    # lift into the ambient space and are fetched for it
-    assert all(out["where_the_blocks_were"]["dim2"][k] == "device" for k in ("flux", "bound_flux", "bound_pressure_cell",
-                                                                              "bound_pressure_face"))
+    # ... and so were those of the fracture planes (2-D grids embedded in 3-D): the lift of their vector-source columns
+    # into the ambient space is a product on the device
+    assert all(v == "device" for v in out["where_the_blocks_were"]["dim2"].values())
     assert max(out["merged_rel_err"].values()) < 1e-10
     assert out["J_pp_rel_err"] < 1e-10 and out["J_pl_rel_err"] < 1e-10 and out["flux_rel_err"] < 1e-10
     assert out["J_pp_shape"] == [100, 100] and out["J_pl_nnz"] > 0
