@@ -20,7 +20,10 @@ def ref_path(prefer_archive: bool = False):
     if not prefer_archive and os.path.isdir(os.path.join(REF_LIVE, "porepy")):
         return [SHIM, REF_LIVE]
     if os.path.exists(REF_ARCHIVE):
-        return [SHIM, REF_ARCHIVE]
+        from . import make_ref
+
+        if make_ref.usable(REF_ARCHIVE):  # (written by another Python minor version: treated as absent)
+            return [SHIM, REF_ARCHIVE]
     if os.path.isdir(os.path.join(REF_LIVE, "porepy")):
         return [SHIM, REF_LIVE]
     return None

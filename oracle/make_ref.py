@@ -18,6 +18,7 @@ entries (import shim + reference) for a subprocess: the live tree when ``/root/r
 """
 from __future__ import annotations
 
+import importlib.util
 import os
 import py_compile
 import sys
@@ -30,6 +31,13 @@ OUT_DIR = os.path.join(HERE, "_ref")
 ARCHIVE = os.path.join(OUT_DIR, "porepy_ref.zip")
 # modules of the reference's own test-suite that a drop-in test subclasses (archive member name -> source)
 EXTRA = {"reference_test_tpfa.pyc": "/root/reference/tests/numerics/fv/test_tpfa.py"}
+# ... and the modules of it that tests/test_reference_suite.py runs under the rebound operators on the GPU box
+# (package ``reference_tests`` of the archive; tests/_reference_suite_runner.py star-imports them into stubs)
+SUITE = ["numerics/fv/test_mpfa", "numerics/fv/test_mpsa", "numerics/fv/test_biot", "numerics/fv/test_tpfa",
+         "numerics/fv/test_fvutils", "models/test_fluid_mass_balance", "models/test_momentum_balance",
+         "models/test_poromechanics"]
+for _m in SUITE:
+    EXTRA["reference_tests/" + os.path.basename(_m) + ".pyc"] = "/root/reference/tests/" + _m + ".py"
 
 
 def build(force: bool = False) -> str | None:
@@ -44,6 +52,8 @@ def build(force: bool = False) -> str | None:
                 p = os.path.join(d, n)
                 files.append(p)
                 newest = max(newest, os.path.getmtime(p))
+    newest = max([newest, os.path.getmtime(os.path.abspath(__file__))] +
+                 [os.path.getmtime(p) for p in EXTRA.values() if os.path.exists(p)])
     if not force and os.path.exists(ARCHIVE) and os.path.getmtime(ARCHIVE) >= newest:
         return ARCHIVE
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -61,8 +71,26 @@ def build(force: bool = False) -> str | None:
             py_compile.compile(src, cfile=cfile, dfile="<reference>/" + os.path.relpath(src, "/root/reference"),
                                doraise=True, invalidation_mode=py_compile.PycInvalidationMode.UNCHECKED_HASH)
             z.write(cfile, member)
+        init_src = os.path.join(scratch, "empty_init.py")
+        open(init_src, "w").close()
+        init_pyc = os.path.join(scratch, "empty_init.pyc")
+        py_compile.compile(init_src, cfile=init_pyc, dfile="<recipe>/reference_tests/__init__.py", doraise=True,
+                           invalidation_mode=py_compile.PycInvalidationMode.UNCHECKED_HASH)
+        z.write(init_pyc, "reference_tests/__init__.pyc")
+        # the interpreter that wrote the members: an archive is only usable by the same bytecode magic
+        z.writestr("PYC_MAGIC", importlib.util.MAGIC_NUMBER.hex())
     os.replace(tmp, ARCHIVE)
     return ARCHIVE
+
+
+def usable(archive: str = ARCHIVE) -> bool:
+    """True when ``archive`` was written by an interpreter with this interpreter's bytecode magic (sourceless
+    ``.pyc`` members do not import under another one)."""
+    try:
+        with zipfile.ZipFile(archive) as z:
+            return z.read("PYC_MAGIC").decode().strip() == importlib.util.MAGIC_NUMBER.hex()
+    except (OSError, KeyError, zipfile.BadZipFile):
+        return False
 
 
 if __name__ == "__main__":

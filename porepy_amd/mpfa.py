@@ -94,6 +94,53 @@ def plane_basis(nodes: np.ndarray, tol: float = 1e-5):
     return np.ascontiguousarray(v[:, [2, 1]].T)
 
 
+def reference_plane_rotation(nodes: np.ndarray, face_centers: np.ndarray, tol: float = 1e-5):
+    """``(R, dim)`` of the reference's ``map_geometry.map_grid`` for a 2-D grid (geometry/map_geometry.py:118-135):
+    the 3 x 3 rotation that turns the plane of the nodes onto a coordinate plane and the mask of the two coordinates
+    that vary afterwards.  Restated because the reference's un-rotation of the vector-source matrices with
+    ``ambient_dimension == 2`` (numerics/fv/mpfa.py:425-462) depends on WHICH rotation was picked: the normal is the
+    longest cross product of the longest centred node vector with the others (``compute_normal``, :440-517), R the
+    Rodrigues rotation about ``normal x e_z`` by the angle between the two (``project_plane_matrix`` :215-270,
+    ``rotation_matrix`` :327-358)."""
+    x = np.asarray(nodes, dtype=float)
+    v = x - x.mean(axis=1).reshape((-1, 1))
+    nrm = np.linalg.norm(v, axis=0)
+    v1 = v[:, int(np.argmax(nrm))]
+    cross = np.array([v1[1] * v[2] - v1[2] * v[1], v1[2] * v[0] - v1[0] * v[2], v1[0] * v[1] - v1[1] * v[0]])
+    normal = cross[:, int(np.argmax(np.linalg.norm(cross, axis=0)))]
+    normal = normal / np.linalg.norm(normal)
+    ref = np.array([0.0, 0.0, 1.0])
+    angle = np.arccos(np.dot(normal, ref))
+    axis = np.cross(normal, ref)
+    if np.allclose(axis, np.zeros(3)):
+        R = np.identity(3)
+    else:
+        axis = axis / np.linalg.norm(axis)
+        W = np.array([[0.0, -axis[2], axis[1]], [axis[2], 0.0, -axis[0]], [-axis[1], axis[0], 0.0]])
+        R = np.identity(3) + np.sin(angle) * W + (1.0 - np.cos(angle)) * (W @ W)
+    fc = R @ np.asarray(face_centers, dtype=float)
+    check = np.sum(np.abs(fc.T - fc[:, 0]), axis=0)
+    check = check / np.sum(check)
+    dim = np.logical_not(np.isclose(check, 0, atol=tol, rtol=0))
+    return R, dim
+
+
+def planar_source_map(sd, T: np.ndarray):
+    """Tilted 2-D grid with ``ambient_dimension == 2``: the (2 Nc x 2 Nc) matrix the reference leaves on the right of
+    the vector-source matrices (mpfa.py:425-462), expressed for matrices computed in the in-plane basis ``T`` of this
+    package.  The reference multiplies its local matrices (basis ``R[dim]``) by rows AND columns ``dim + 2 c`` of
+    blockdiag(R, ..., R) -- the leading 2 Nc x 2 Nc corner of a matrix of 3 x 3 blocks; reproduced as it is."""
+    import scipy.sparse as sps
+
+    R, dim = reference_plane_rotation(sd.nodes, sd.face_centers)
+    nc = sd.num_cells
+    to_ref_basis = sps.kron(sps.identity(nc, format="csr"), sps.csr_matrix(T @ R[dim].T), format="csr")
+    full = sps.kron(sps.identity(nc, format="csr"), sps.csr_matrix(R), format="csr")
+    idx = (np.where(dim)[0].reshape((-1, 1)) + 2 * np.arange(nc)).ravel("F")
+    corner = full[idx][:, idx]
+    return (to_ref_basis @ corner).tocsr()
+
+
 def grid_fingerprint(sd) -> tuple:
     """Cheap digest of what `_upload_grid` reads from ``sd``: sizes, a strided checksum of the node and
     face-centre coordinates, and the periodic map.  Not cryptographic -- it catches the cases the
@@ -438,8 +485,6 @@ class Mpfa:
             raise NotImplementedError("periodic faces: full discretization with conditions per face only")
         kval = np.asarray(k.values, dtype=float)
         if T is not None:
-            if vdim != 3:
-                raise NotImplementedError("a 2-D grid outside the xy-plane needs ambient_dimension = 3")
             # rotate the tensor into the plane (mpfa.py:748-754)
             k2 = np.einsum("ia,abn,jb->ijn", T, kval, T)
             kval = np.zeros_like(kval)
@@ -489,6 +534,9 @@ class Mpfa:
 
             basis = T if T is not None else np.eye(2, 3)
             lift = sps.kron(sps.identity(sd.num_cells, format="csr"), sps.csr_matrix(basis), format="csr")
+        elif sd.dim == 2 and T is not None:
+            # ambient_dimension == 2 on a grid outside the xy-plane: what the reference's un-rotation leaves
+            lift = planar_source_map(sd, T)
         simple = merge is None and order is None and rows is None and not (partial and update)
 
         def lifted(m, L=lift):
@@ -618,6 +666,8 @@ class Mpfa:
             T = self._plane.get(id(sd))
             basis = T if T is not None else np.eye(2, 3)
             vs = (vs.reshape(sd.num_cells, 3) @ basis.T).ravel()
+        elif sd.dim == 2 and self._plane.get(id(sd)) is not None:
+            vs = planar_source_map(sd, self._plane[id(sd)]) @ vs
         return vs
 
     # ---- solve (stand-in for SolutionStrategy.solve_linear_system) --------------------

@@ -221,7 +221,7 @@ def check_tilted_case(lib, name: str):
     g = pa.grid_from_raw(c.grid)
     K = type("K", (), {"values": c.perm})()
     data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": _RawBC(c.bc), "bc_values": c.bc_values,
-                                           "ambient_dimension": 3, "vector_source": c.vector_source_values})
+                                           "ambient_dimension": c.vdim, "vector_source": c.vector_source_values})
     d = pa.Mpfa("flow", library=lib)
     d.discretize(g, data)
     for k in ALL_KEYS:
@@ -236,7 +236,7 @@ def check_tilted_case(lib, name: str):
     from porepy_amd.lazy import LazyCsr
 
     lazy = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": _RawBC(c.bc), "bc_values": c.bc_values,
-                                           "ambient_dimension": 3, "vector_source": c.vector_source_values})
+                                           "ambient_dimension": c.vdim, "vector_source": c.vector_source_values})
     dl = pa.Mpfa("flow", library=lib, lazy=True)
     dl.discretize(g, lazy)
     ml = lazy[pa.DISCRETIZATION_MATRICES]["flow"]

@@ -147,7 +147,7 @@ def test_partial_discretization_one_cell_at_a_time(lib):
     P.partial_one_cell_at_a_time(lib)
 
 
-@pytest.mark.parametrize("name", ["tilted_cart2d_4x3", "tilted_tri2d_4x4", "tilted_flat_tri2d_3x3",
+@pytest.mark.parametrize("name", ["tilted_cart2d_4x3", "tilted_tri2d_4x4", "tilted_flat_tri2d_3x3", "tilted_vdim2_cart2d_4x3", "tilted_vdim2_tri2d_4x4",
                                   # subdomains of a mixed-dimensional grid (oracle/gen_golden_md.py): 3-D matrix with
                                   # fracture faces, 2-D fracture grids in the planes x = 0.5 / y = 0.5
                                   "tilted_md_box_matrix3d", "tilted_md_box_fracture0", "tilted_md_box_fracture1"])
