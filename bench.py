@@ -460,7 +460,36 @@ def bench_operator_api(pa, lp, Kvals, flags, bv, src, eta, device_index: int):
     return out
 
 
+def self_launch_if_needed():
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks of
+    this node here -- the same ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1`` line the contract names, replacing this process, so rank 0's JSON line is this command's stdout."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["PFV_BENCH_SELF_LAUNCHED"] = "1"
+    print("bench.py: launching", " ".join(cmd), file=sys.stderr, flush=True)
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
+    self_launch_if_needed()
     # stdout carries exactly one line, the JSON record: everything else this process or its libraries print
     # (RCCL writes a version banner to the C-level stdout when a communicator is created) goes to stderr
     sys.stdout.flush()

@@ -160,6 +160,7 @@ struct pfv_ctx_impl {
   Buf<double> tab;            // [tab_len]
   Buf<double> tabb;           // [tabb_len] boundary nodes: T[:, lb] beta_lb (n x nb), then A^-1[:, lb] beta_lb
   Buf<SfRec> sf_rec;          // [nsf] see SfRec
+  Buf<int32_t> face_ctr;      // work counters of the face kernel, one per XCD at 64-byte spacing (PFV_FACE_DYN)
   Buf<FaceRec> face_rec;      // [nf] see FaceRec (written at the end of the symbolic phase)
   Buf<int32_t> status;        // [4] device status words: singular node, ...
 
