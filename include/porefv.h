@@ -16,6 +16,7 @@
 #ifndef POREFV_H
 #define POREFV_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -115,6 +116,8 @@ typedef struct {
   int64_t amg_level0_nnz;         /* entries of the matrix the finest level of the cycle smooths with: nnz of the system,
                                      or of its strength-filtered copy (PFV_AMG_FILTER_PERMIL, scalar systems: default) */
   double amg_filter_theta;        /* threshold of that filter (0: off) */
+  int64_t win_reused;             /* 1: the last discretize kept the SpMV windows of A -- the symbolic phase proved A's
+                                     pattern equal (sizes + checksum of the index arrays) to the one they were built for */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);
@@ -500,6 +503,9 @@ pfv_status pfv_reset_stream(pfv_ctx* h);
 pfv_status pfv_sync(pfv_ctx* h);
 
 pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out);
+/* the same for a caller compiled against another revision of this header: writes at most `struct_size` bytes
+ * (= the caller's sizeof(pfv_stats); fields are only ever appended), so a shorter struct is never overrun */
+pfv_status pfv_get_stats_n(pfv_ctx* h, void* out, size_t struct_size);
 
 /* Measurement hook for bench.py: average duration (ms, HIP events on the handle's stream)
  * of `reps` back-to-back launches of one kernel on the data currently in the handle.

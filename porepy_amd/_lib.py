@@ -42,7 +42,7 @@ EXPORTS = [
     "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
     "pfv_rccl_unique_id", "pfv_rccl_comm_create", "pfv_rccl_set_halo_plan", "pfv_rccl_hooks", "pfv_rccl_stats",
     "pfv_rccl_last_error", "pfv_rccl_comm_destroy", "pfv_mpfa_ad_flux_system", "pfv_host_alloc", "pfv_host_free",
-    "pfv_mpsa_set_subface_eta", "pfv_mpsa_set_reconstruction_eta",
+    "pfv_mpsa_set_subface_eta", "pfv_mpsa_set_reconstruction_eta", "pfv_get_stats_n",
 ]
 
 
@@ -60,7 +60,8 @@ class Stats(C.Structure):
                 ("amg_operator_complexity", C.c_double), ("amg_levels", C.c_int64),
                 ("amg_coarsest_rows", C.c_int64), ("discretize_ms", C.c_double), ("solve_renumbered", C.c_int64),
                 ("node_flops", C.c_double), ("node_table_doubles", C.c_int64),
-                ("amg_maps_reused", C.c_int64), ("amg_level0_nnz", C.c_int64), ("amg_filter_theta", C.c_double)]
+                ("amg_maps_reused", C.c_int64), ("amg_level0_nnz", C.c_int64), ("amg_filter_theta", C.c_double),
+                ("win_reused", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -197,6 +198,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_sync.restype = C.c_int
     lib.pfv_get_stats.argtypes = [_h, C.POINTER(Stats)]
     lib.pfv_get_stats.restype = C.c_int
+    lib.pfv_get_stats_n.argtypes = [_h, C.c_void_p, C.c_size_t]
+    lib.pfv_get_stats_n.restype = C.c_int
     lib.pfv_time_kernel.argtypes = [_h, C.c_int, C.c_int, _dp]
     lib.pfv_time_kernel.restype = C.c_int
     lib.pfv_mpfa_ad_flux_system.argtypes = [_h, _dp, _dp, _dp, _dp, _dp, _dp, C.c_uint32]
@@ -897,7 +900,7 @@ class Context:
 
     def stats(self) -> dict:
         s = Stats()
-        self._check(self.lib.pfv_get_stats(self._h, C.byref(s)))
+        self._check(self.lib.pfv_get_stats_n(self._h, C.byref(s), C.sizeof(s)))
         return s.as_dict()
 
     def sync(self):

@@ -249,6 +249,9 @@ struct pfv_ctx_impl {
   int precond = 0;                   // PFV_PRECOND_*
   std::unique_ptr<Amg> amg;          // hierarchy of the active system (rebuilt when the system changes)
   const double* amg_for_val = nullptr;  // the matrix values the hierarchy was built from
+  Buf<unsigned long long> csum_work;       // partial sums of launch_pattern_checksum
+  unsigned long long pat_A_checksum = 0;   // checksum of pat_A's index arrays left by the symbolic phase (0: none)
+  unsigned long long win_sys_checksum = 0; // ... of the pattern win_sys was built for (0: unknown)
   unsigned long long symbolic_epoch = 0;  // bumped by every symbolic phase: saved AMG aggregates die with it
   std::unique_ptr<Amg> amg_block;    // pfv_amg_setup: hierarchy of the leading block (sharded solves)
   CsrPattern pat_block;

@@ -4,6 +4,7 @@
 // Build (emulation): g++ -x c++ -DPFV_EMULATE -O2 -std=c++17 -shared -fPIC porefv.hip
 //                    (test infrastructure; see backend.h)
 #include <cmath>
+#include <cstring>
 
 #include "ctx.h"
 #include "topology.inc"
@@ -399,7 +400,17 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
         h->stream = h->aux_stream;
         try {
           if (prebuild) {
-            pfv::win_build(*h, h->pat_A, h->win_sys);
+            // the windows are a function of A's pattern alone: kept when the symbolic phase has just proved the
+            // pattern equal to the one they were built for (sizes + checksum of the index arrays)
+            const bool keep = h->win_sys.ok && h->pat_A_checksum != 0 && h->win_sys_checksum == h->pat_A_checksum &&
+                              h->win_sys.nrows == h->pat_A.nrows && h->win_sys.nnz == h->pat_A.nnz &&
+                              pfv::env_int("PFV_WIN_REUSE", 1) != 0;
+            h->stats.win_reused = keep ? 1 : 0;
+            if (!keep) {
+              h->win_sys_checksum = 0;
+              pfv::win_build(*h, h->pat_A, h->win_sys);
+              if (h->win_sys.ok) h->win_sys_checksum = h->pat_A_checksum;
+            }
           } else {
             RowsView rows(h->pat_A, h->win_rows_n);
             pfv::win_build(*h, rows.V, h->win_rows);
@@ -1476,6 +1487,7 @@ static pfv::LinSys solver_system(pfv_ctx* h, bool& permuted) {
   sys.win = nullptr;
   if (sys.P->nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000)) {
     if (h->win_for != sys.P->indices.p || !h->win_sys.ok || pfv::env_int("PFV_SPMV_WINDOW", 1) == 0) {
+      h->win_sys_checksum = 0;
       pfv::win_build(*h, *sys.P, h->win_sys);
       h->win_for = sys.P->indices.p;
     }
@@ -1615,6 +1627,13 @@ pfv_status pfv_get_stats(pfv_ctx* h, pfv_stats* out) {
   return guarded(h, [&] {
     require(out != nullptr, "null output");
     *out = h->stats;
+  });
+}
+
+pfv_status pfv_get_stats_n(pfv_ctx* h, void* out, size_t struct_size) {
+  return guarded(h, [&] {
+    require(out != nullptr, "null output");
+    std::memcpy(out, &h->stats, std::min(struct_size, sizeof(pfv_stats)));
   });
 }
 

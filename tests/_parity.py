@@ -677,12 +677,23 @@ def amg_preconditioner(lib, g, seed=2, hetero_sigma=0.5):
     assert st2["amg_maps_reused"] == 1
     assert ir["converged"] and np.linalg.norm(xr - xo2) <= TOL * np.linalg.norm(xo2)
     assert ir["iterations"] <= out["bicgstab"] + 4, (ir["iterations"], out)
-    # a rebuilt discretization (new symbolic phase) never reuses
+    # a rebuilt discretization (new sub-cell topology, new symbolic phase) reuses exactly when its pattern is proved
+    # equal to the saved one -- sizes and the checksum of A's index arrays the symbolic phase leaves; with
+    # PFV_AMG_REUSE_REBUILT=0 the symbolic phase itself has to be the same one
     data[pa.PARAMETERS]["flow"]["hip_rebuild_topology"] = True
     d.discretize(g, data)
     d.assemble_matrix_rhs(g, data)
     xf, i_f = d.solve(g, data, source=src, method="bicgstab", rtol=1e-12, precond="amg")
-    assert d.context(g).stats()["amg_maps_reused"] == 0
+    assert d.context(g).stats()["amg_maps_reused"] == 1
+    assert np.array_equal(xf, xr) and i_f["iterations"] == ir["iterations"]  # same aggregates, same values: same bits
+    os.environ["PFV_AMG_REUSE_REBUILT"] = "0"
+    try:
+        d.discretize(g, data)
+        d.assemble_matrix_rhs(g, data)
+        xf, i_f = d.solve(g, data, source=src, method="bicgstab", rtol=1e-12, precond="amg")
+        assert d.context(g).stats()["amg_maps_reused"] == 0
+    finally:
+        del os.environ["PFV_AMG_REUSE_REBUILT"]
     assert np.linalg.norm(xf - xo2) <= TOL * np.linalg.norm(xo2)
     return out, ij["iterations"], st
 
