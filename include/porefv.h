@@ -398,11 +398,12 @@ pfv_status pfv_amg_apply_device(pfv_ctx* h, const double* d_r, double* d_z);
  * SolutionStrategy.solve_linear_system (models/solution_strategy.py:830-884).
  *   exchange_halo(user, d_x, stream): entries [n_own, n_local) of the SpMV input d_x are to be
  *     filled from their owners (RCCL ncclSend / ncclRecv over xGMI); the owned entries are current;
- *   allreduce_sum(user, d_vals, count, stream): in-place sum over the ranks of count (<= 2) doubles
- *     in device memory (ncclAllReduce) -- one call per fused pair of dot products.
+ *   allreduce_sum(user, d_vals, count, stream): in-place sum over the ranks of count (<= 8) doubles
+ *     in device memory (ncclAllReduce) -- one call per fused group of dot products (BiCGStab: two calls per
+ *     iteration, of 2 and 5 sums: the sums of the vector update ride with those of omega).
  * Both run on the calling thread between kernel launches and must only enqueue work ordered with
  * `stream` (the handle's hipStream_t as void*, see pfv_set_stream); a non-zero return aborts the
- * solve with PFV_ERR_ARGUMENT.  d_work: 2 * n_local + 2 doubles of caller device memory (the two
+ * solve with PFV_ERR_ARGUMENT.  d_work: 2 * n_local + 8 doubles of caller device memory (the two
  * SpMV inputs d_x the hooks see are d_work and d_work + n_local, d_vals is d_work + 2 * n_local).
  * Preconditioner as selected by pfv_set_preconditioner: Jacobi, or one cycle of the block hierarchy
  * of pfv_amg_setup(n_own) (block Jacobi across ranks, no communication inside).  Every rank takes

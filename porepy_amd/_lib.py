@@ -946,7 +946,7 @@ class Context:
         """The fused Krylov loop on the leading ``n_own`` rows of the assembled system (pfv_solve_sharded).
         ``exchange_halo(d_x_ptr)`` fills the halo entries of the SpMV input at that address,
         ``allreduce_sum(d_vals_ptr, count)`` sums ``count`` doubles over the ranks in place; both only
-        enqueue work on the handle's stream.  ``work_ptr``: 2 n_local + 2 doubles of device memory (the
+        enqueue work on the handle's stream.  ``work_ptr``: 2 n_local + 8 doubles of device memory (the
         addresses the hooks see point into it), ``x_ptr``: n_own doubles for the solution."""
         code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB}[method]
         self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1}[precond]))

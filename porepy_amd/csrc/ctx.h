@@ -258,7 +258,8 @@ struct pfv_ctx_impl {
   Buf<double> val_block;
   // set only while pfv_solve_sharded runs: the caller's exchange hooks and work space
   const pfv_shard_hooks* shard = nullptr;
-  double* shard_work = nullptr;      // [2 * shard_nloc + 2]: the two SpMV inputs (owned + halo entries), reduction scratch
+  Buf<double> red5;                  // block partials of the sharded BiCGStab's five merged sums
+  double* shard_work = nullptr;      // [2 * shard_nloc + 8]: the two SpMV inputs (owned + halo entries), reduction scratch
   int64_t shard_nloc = 0;
 
   pfv_stats stats{};

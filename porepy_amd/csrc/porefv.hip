@@ -1597,7 +1597,7 @@ pfv_status pfv_solve_sharded(pfv_ctx* h, int method, double rtol, int maxit, int
       Mp = &M;
     }
     pfv::be_memset(d_x_owned, 0, sizeof(double) * (size_t)n_own, s);
-    pfv::be_memset(d_work, 0, sizeof(double) * (size_t)(2 * n_loc + 2), s);
+    pfv::be_memset(d_work, 0, sizeof(double) * (size_t)(2 * n_loc + 8), s);
     h->shard = hooks;
     h->shard_work = d_work;
     h->shard_nloc = n_loc;

@@ -427,7 +427,7 @@ class ShardedMpfa:
         self.plan.exchange(x_full)
         self.ctx.spmv_device_rows(self.system_matrix, self.n_own, x_full.data_ptr(), out_owned.data_ptr())
 
-    def solve(self, method: str = "bicgstab", rtol: float = 1e-10, maxit: int = 20000, check_every: int = 10,
+    def solve(self, method: str = "bicgstab", rtol: float = 1e-10, maxit: int = 20000, check_every: int | None = None,
               precond: str = "jacobi", driver: str = "library"):
         """Returns (x_owned as a torch tensor, info).  precond = "amg": one cycle of the coupled aggregation AMG
         (``amg_setup``: every level exchanges its halo values, the coarse levels are gathered and replicated -- the
@@ -441,9 +441,24 @@ class ShardedMpfa:
         (point-to-point) and one all-reduce per fused pair of dot products.  driver = "torch": the same
         iteration spelled out in torch ops around ``pfv_spmv_device_rows`` (kept as the cross-check)."""
         if driver == "library":
-            return self._solve_library(method, rtol, maxit, precond)
+            # check_every: iterations between two reads of the (all-reduced) residual by the host; None = the library's
+            # default (PFV_SHARD_CHECK_EVERY, 4: up to three iterations past convergence, no stream drain in between)
+            import os
+
+            saved = os.environ.get("PFV_SHARD_CHECK_EVERY")
+            if check_every is not None:
+                os.environ["PFV_SHARD_CHECK_EVERY"] = str(int(check_every))
+            try:
+                return self._solve_library(method, rtol, maxit, precond)
+            finally:
+                if check_every is not None:
+                    if saved is None:
+                        os.environ.pop("PFV_SHARD_CHECK_EVERY", None)
+                    else:
+                        os.environ["PFV_SHARD_CHECK_EVERY"] = saved
         if driver != "torch":
             raise ValueError("driver must be 'library' or 'torch'")
+        check_every = 10 if check_every is None else check_every
         torch = self.torch
         n, dev = self.n_own, self.device
         self._use_torch_stream()
@@ -655,7 +670,7 @@ class ShardedMpfa:
             if want and self._amg_ready != want:
                 self.amg_setup(coupled=precond == "amg", native=native)
             precond = "amg" if want else precond
-            work = torch.empty(2 * nloc + 2, dtype=torch.float64, device=dev)
+            work = torch.empty(2 * nloc + 8, dtype=torch.float64, device=dev)
             x = torch.empty(n, dtype=torch.float64, device=dev)
             torch.cuda.current_stream(dev).synchronize()  # the buffers exist before the handle's stream uses them
             info = self.ctx.solve_sharded(n, native, None, work.data_ptr(), x.data_ptr(),
@@ -670,7 +685,7 @@ class ShardedMpfa:
         if want and self._amg_ready != want:
             self.amg_setup(coupled=precond == "amg")
         precond = "amg" if want else precond
-        work = torch.empty(2 * nloc + 2, dtype=torch.float64, device=dev)
+        work = torch.empty(2 * nloc + 8, dtype=torch.float64, device=dev)
         x = torch.empty(n, dtype=torch.float64, device=dev)
         views = {work.data_ptr(): work[:nloc], work.data_ptr() + 8 * nloc: work[nloc:2 * nloc]}
         red = work[2 * nloc:]
@@ -681,16 +696,17 @@ class ShardedMpfa:
             self.plan.exchange(views[ptr])
 
         def allreduce_sum(ptr, count):
-            if ptr != red_ptr or count > 2:
+            if ptr != red_ptr or count > 8:
                 raise RuntimeError("unexpected reduction buffer")
             if multi:
+                part = red[:count]
                 # gloo cannot reduce device tensors in place on every build: stage through the host there
                 if red.is_cuda and self.dist.get_backend() == "gloo":
-                    h = red.cpu()
+                    h = part.cpu()
                     self.dist.all_reduce(h)
-                    red.copy_(h)
+                    part.copy_(h)
                 else:
-                    self.dist.all_reduce(red)
+                    self.dist.all_reduce(part)
 
         try:
             info = self.ctx.solve_sharded(n, exchange_halo, allreduce_sum, work.data_ptr(), x.data_ptr(),

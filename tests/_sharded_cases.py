@@ -61,7 +61,7 @@ def worker(rank, world, port, n_side, out, env=None):
         res = {}
         for precond in ("amg", "amg_block"):
             t0 = time.time()
-            x, info = sh.solve(method="bicgstab", rtol=1e-10, maxit=500, precond=precond)
+            x, info = sh.solve(method="bicgstab", rtol=1e-10, maxit=500, precond=precond, check_every=1)
             st = sh.ctx.stats()
             res[precond] = {"iterations": info["iterations"], "converged": info["converged"],
                             "rel_residual": info["rel_residual"], "seconds": time.time() - t0,

@@ -249,14 +249,25 @@ def _slab_worker(rank, world, port, out, strong=False, blocks=None):
         sh = D.ShardedMpfa(lp, device="cpu", library=lib, dist=dist)
         sh.discretize(Kv, flags, None, eta)
         sh.assemble(bv, src)
-        x, info = sh.solve("bicgstab", rtol=1e-12, maxit=3000, check_every=1, precond="amg" if blocks else "jacobi")
-        torch.save({"gid": lp.cell_gid[: lp.n_own], "x": x.numpy(), "info": info, "peers": sorted(sh.plan.send_cells)},
-                   os.path.join(out, f"s{rank}.pt"))
+        # 2 x 2 x 2: the library's defaults (merged reductions, residual read every 4 iterations), as bench.py runs it
+        x, info = sh.solve("bicgstab", rtol=1e-12, maxit=3000, check_every=None if world == 8 else 1,
+                           precond="amg" if blocks else "jacobi")
+        extra = {}
+        if world == 8:
+            # the textbook loop (three all-reduces per iteration) on the same system: same solution, the merged loop
+            # stops within its check interval of it
+            os.environ["PFV_SHARD_MERGED_DOTS"] = "0"
+            x3, info3 = sh.solve("bicgstab", rtol=1e-12, maxit=3000, check_every=1, precond="amg")
+            del os.environ["PFV_SHARD_MERGED_DOTS"]
+            extra = {"x_unmerged": x3.numpy(), "info_unmerged": info3}
+        torch.save({"gid": lp.cell_gid[: lp.n_own], "x": x.numpy(), "info": info, "peers": sorted(sh.plan.send_cells),
+                    **extra}, os.path.join(out, f"s{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("strong", [False, True, (1, 2, 2)], ids=["weak-slabs", "strong-slabs", "strong-blocks-1x2x2"])
+@pytest.mark.parametrize("strong", [False, True, (1, 2, 2), (2, 2, 2)],
+                         ids=["weak-slabs", "strong-slabs", "strong-blocks-1x2x2", "strong-blocks-2x2x2-8-ranks"])
 def test_bench_slab_decomposition_matches_single_domain(tmp_path, strong):
     """The slab problems bench.py builds per rank (no global grid) are one global problem:
     3 ranks x 3 lattice layers reproduce the 9-layer single-domain solution (weak scaling); the
@@ -269,7 +280,7 @@ def test_bench_slab_decomposition_matches_single_domain(tmp_path, strong):
     import bench
 
     blocks = strong if isinstance(strong, tuple) else None
-    world = 4 if blocks else 3
+    world = blocks[0] * blocks[1] * blocks[2] if blocks else 3
     P.emulation_library()  # build once here, not concurrently in the workers
     mp.spawn(_slab_worker, args=(world, _free_port(), str(tmp_path), bool(strong), blocks), nprocs=world, join=True)
     lib = P.emulation_library()
@@ -291,9 +302,18 @@ def test_bench_slab_decomposition_matches_single_domain(tmp_path, strong):
         o = torch.load(os.path.join(str(tmp_path), f"s{r}.pt"), weights_only=False)
         assert o["info"]["converged"]
         if blocks:
-            assert len(o["peers"]) == 3  # face neighbour in y, in z, and the block across the edge
+            # 1 x 2 x 2: face neighbour in y, in z, and the block across the edge; 2 x 2 x 2 (what bench.py --gpus 8
+            # cuts): three face, three edge neighbours and the block across the corner
+            assert len(o["peers"]) == (7 if world == 8 else 3)
         want = np.array([ref_by_gid[g] for g in o["gid"].tolist()])
         assert np.linalg.norm(o["x"] - want) <= 1e-9 * np.linalg.norm(x_ref)
+        if world == 8:
+            i3 = o["info_unmerged"]
+            assert i3["converged"] and np.linalg.norm(o["x_unmerged"] - want) <= 1e-9 * np.linalg.norm(x_ref)
+            # same iteration up to rounding: the merged loop stops at the first multiple of 4 at or past the count of
+            # the loop that reads the residual every iteration (+1: the recursive residual of the expanded form)
+            assert i3["iterations"] <= o["info"]["iterations"] <= i3["iterations"] + 4, (i3["iterations"], o["info"]["iterations"])
+            assert o["info"]["iterations"] % 4 == 0
         total += o["gid"].size
     assert total == lp.n_own
 
