@@ -303,7 +303,10 @@ def make_slab_problem(n_side: int, rank: int, world: int, layers: int | None = N
     return lp, K.values, flags, bv, src, 1.0 / 3.0
 
 
-def cpu_baseline_reference(n_side: int, timeout_s: float = 480.0):
+CPU_THREADS = 16  # BLAS / OpenMP threads handed to the reference's CPU run (stated as cpu_baseline.cores)
+
+
+def cpu_baseline_reference(n_side: int, timeout_s: float = 480.0, num_sub: int = 1, solve_cap_s: float = 0.0):
     """PorePy's OWN scipy/numpy CPU path timed on this box's host cores (kind "reference"):
     ``pp.Mpfa("flow").discretize`` (``mpfa_inverter="python"``: numba is absent) + ``assemble_matrix_rhs`` + the
     linear solve, run by ``oracle/ref_cpu_baseline.py`` in a subprocess that imports the reference from the live
@@ -316,8 +319,10 @@ def cpu_baseline_reference(n_side: int, timeout_s: float = 480.0):
     env = oracle.ref_env()
     if env is None:
         return None
+    env["OMP_NUM_THREADS"] = env["OPENBLAS_NUM_THREADS"] = str(CPU_THREADS)
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_cpu_baseline.py"), str(n_side)],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_cpu_baseline.py"), str(n_side),
+                            str(num_sub), str(solve_cap_s)],
                            env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
         if not line:
@@ -328,11 +333,14 @@ def cpu_baseline_reference(n_side: int, timeout_s: float = 480.0):
     total = o["discretize_s"] + o["assemble_s"] + o["solve_s"]
     return {
         "value": o["cells"] / total, "unit": "cells/s",
-        "cores": max(1, int(round(o.get("effective_threads", 1.0)))), "kind": "reference",
+        # threads the run was given (OMP_NUM_THREADS = OPENBLAS_NUM_THREADS); its hot loops -- scipy's csr_matmat and
+        # the Python loop over np.linalg.inv blocks -- are serial, see threads_busy_on_average
+        "cores": CPU_THREADS, "threads_busy_on_average": o.get("effective_threads", 1.0), "kind": "reference",
+        "num_subproblems": o.get("num_subproblems", 1),
         "sample": f"PorePy itself (imported from {'the byte-compiled archive oracle/_ref' if o['porepy_from'].find('.zip') >= 0 else 'the reference tree'}): "
                   f"{o['cells']} tetrahedra (n_side={n_side}{', BASELINE configs[1] size' if n_side == 32 else ''}) of the timed workload family "
                   f"(perturbed nodes, anisotropic heterogeneous K): pp.Mpfa.discretize {o['discretize_s']:.1f} s "
-                  f"(mpfa_inverter='python', numba absent) + assemble_matrix_rhs {o['assemble_s']:.2f} s + solve "
+                  f"(mpfa_inverter='python', numba absent{'' if o.get('num_subproblems', 1) <= 1 else ', partition_arguments num_subproblems=' + str(o['num_subproblems'])}) + assemble_matrix_rhs {o['assemble_s']:.2f} s + solve "
                   f"{o['solve_s']:.1f} s [{o['solver']}; {o['iterations']} iterations, true residual {o['rel_residual']:.1e}]; "
                   f"peak RSS {o['peak_rss_gb']:.1f} GB; host has {o['host_cores']} cores, process CPU time / wall time = "
                   f"{o.get('effective_threads', 1.0):.2f} threads busy (scipy csr_matmat and the Python loop of "
@@ -396,7 +404,7 @@ def load_pmc(n_side: int, world: int) -> dict:
     """HBM traffic per launch from the PMC passes of tools/gpu_pmc.sh (FETCH_SIZE and WRITE_SIZE in separate
     runs), if profiles/ holds a file collected with exactly this build on this workload; else {}."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as fh:
             pj = json.load(fh)
         if pj.get("n_side") == n_side and world == 1 and pj.get("source_hash") == source_hash():
             return pj["kernels"]
@@ -513,6 +521,10 @@ def main():
                     help="lattice side of the reference's CPU run (32 = 196 608 cells, BASELINE configs[1] size: ~2 min)")
     ap.add_argument("--cpu-port-n-side", type=int, default=16, help="size of the oracle-port fallback")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-headline", type=int, default=0, metavar="K",
+                    help="also time the reference on the HEADLINE grid itself (configs[2] size) with "
+                         "partition_arguments={'num_subproblems': K} (SURVEY 8(d)); minutes of host time: off by default, "
+                         "the record of such a run is kept under profiles/")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the secondary lines for BASELINE configs[1] and configs[3] (profiling runs)")
@@ -808,8 +820,11 @@ def main():
                      "tight_solve_true_rel_residual": info2["rel_residual"], "tight_solve_iterations": info2["iterations"]}
         except Exception as e:  # diagnostics only
             field = {"error": repr(e)}
+    cpu_headline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_n_side, args.cpu_port_n_side)
+    if rank == 0 and world == 1 and args.cpu_headline > 0:
+        cpu_headline = cpu_baseline_reference(args.n_side, timeout_s=3000.0, num_sub=args.cpu_headline, solve_cap_s=600.0)
     if rank == 0 and world == 1 and not args.force_sharded and args.n_side == 69 and not args.no_extra_configs:
         try:
             opapi = bench_operator_api(pa, lp, Kvals, flags, bv, src, eta, local_rank)
@@ -853,6 +868,19 @@ def main():
                                                      "replicated: pfv_amg_setup_sharded)",
                                               "amg_block": "block Jacobi across ranks (pfv_amg_setup(n_own))"}.get(args.precond)),
                        "solve_on_renumbered_copy": bool(st.get("solve_renumbered", 0)),
+                       "ranks_seen_by_rccl": (dist.get_world_size() if dist is not None else 1),
+                       "process_group_backend": (dist.get_backend() if dist is not None else None),
+                       "self_launched": os.environ.get("PFV_BENCH_SELF_LAUNCHED") == "1",
+                       "pattern_reuse": {"amg_aggregate_maps_kept": int(st.get("amg_maps_reused", 0)),
+                                         "spmv_windows_kept": int(st.get("win_reused", 0)),
+                                         "note": "every step rebuilds the sub-cell topology, all CSR patterns, all values, the "
+                                                 "strength filter, the Galerkin products and the solve; the aggregate maps of the "
+                                                 "AMG levels and the SpMV windows of A -- functions of A's pattern -- are kept when "
+                                                 "the symbolic phase proves the new pattern equal (sizes + 64-bit checksum of the "
+                                                 "index arrays); PFV_AMG_REUSE_REBUILT=0 PFV_WIN_REUSE=0 rebuilds them too"},
+                       "sparsity_pattern": "structural stencil: a superset of the reference's stored pattern (bit-identical on "
+                                           "generic anisotropic inputs; where the reference's sparse products drop exact zeros, "
+                                           "what is stored outside its pattern is < 1e-12 of the row maximum)",
                        "iterations": info["iterations"], "converged": info["converged"],
                        "true_rel_residual": res_true, "field_error": field,
                        "global_cells": ncells_total,
@@ -864,7 +892,8 @@ def main():
                        "AMG: per level and visit 2 point-to-point halo exchanges, one all-gather at the gathered level"},
             "roofline": roofline, "roofline_kernels": kernels[1:], "kernel_ms_per_step": per_step_ms,
             "hbm_triad_measured_GBs": triad_gbs, "hbm_read_stream_measured_GBs": read_gbs,
-            "assembly": assembly, "operator_api": opapi, "cpu_baseline": cpu, "config_c2": c2, "config_c4": c4,
+            "assembly": assembly, "operator_api": opapi, "cpu_baseline": cpu, "cpu_baseline_headline_grid": cpu_headline,
+            "config_c2": c2, "config_c4": c4,
         }
         if args.phases:
             print(json.dumps(st, indent=1), file=sys.stderr)

@@ -1,7 +1,10 @@
 """The REFERENCE's own CPU path, timed (bench.py: cpu_baseline, kind "reference").
 
 TEST INFRASTRUCTURE; run as a subprocess with the reference importable (``oracle.ref_env()``):
-    python oracle/ref_cpu_baseline.py N_SIDE
+    python oracle/ref_cpu_baseline.py N_SIDE [NUM_SUBPROBLEMS [SOLVE_CAP_S]]
+NUM_SUBPROBLEMS > 1: ``partition_arguments={"num_subproblems": k}`` (mpfa.py:160-161, 246-372: the reference's own
+memory-bounded split -- what SURVEY 8(d) prescribes for configs[2] / [3] sizes); SOLVE_CAP_S bounds the Krylov solve
+(the line then reports the residual reached).
 Times, on one grid object and with the reference's own classes only,
   (i)   ``pp.Mpfa("flow").discretize(g, data)`` with ``mpfa_inverter="python"`` (numba is absent)
         — /root/reference/src/porepy/numerics/fv/mpfa.py:65-508;
@@ -28,7 +31,7 @@ import porepy as pp
 DIRECT_MAX = 30000
 
 
-def main(n_side: int):
+def main(n_side: int, num_sub: int = 1, solve_cap_s: float = 0.0):
     t00 = time.perf_counter()
     g = pp.StructuredTetrahedralGrid([n_side] * 3, [1.0, 1.0, 1.0])
     g.compute_geometry()
@@ -50,8 +53,10 @@ def main(n_side: int):
     bc = pp.BoundaryCondition(g, dirf, ["dir"] * dirf.size)
     bv = np.zeros(g.num_faces)
     bv[dirf] = g.face_centers[0, dirf]
-    data = pp.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": bv,
-                                              "mpfa_inverter": "python"})
+    params = {"second_order_tensor": K, "bc": bc, "bc_values": bv, "mpfa_inverter": "python"}
+    if num_sub > 1:
+        params["partition_arguments"] = {"num_subproblems": int(num_sub)}
+    data = pp.initialize_data({}, "flow", params)
     t_grid = time.perf_counter() - t00
     discr = pp.Mpfa("flow")
     c0 = time.process_time()
@@ -69,11 +74,22 @@ def main(n_side: int):
         M = sps.diags(1.0 / A.diagonal())
         its = 0
 
-        def cb(_):
+        class _Cap(Exception):
+            pass
+
+        last = [None]
+
+        def cb(xk):
             nonlocal its
             its += 1
+            last[0] = xk
+            if solve_cap_s > 0 and time.perf_counter() - t2 > solve_cap_s:
+                raise _Cap()
 
-        p, flag = spla.bicgstab(A, b, rtol=1e-10, atol=0.0, maxiter=20000, M=M, callback=cb)
+        try:
+            p, flag = spla.bicgstab(A, b, rtol=1e-10, atol=0.0, maxiter=20000, M=M, callback=cb)
+        except _Cap:
+            p, flag = np.array(last[0], copy=True), f"stopped at the {solve_cap_s:.0f} s cap"
         solver = f"scipy BiCGStab+Jacobi rtol 1e-10 (flag {flag}); the reference's direct solve does not finish at this size"
     t3 = time.perf_counter()
     cpu_s = time.process_time() - c0  # all threads of this process: cpu_s / wall = threads effectively busy
@@ -88,9 +104,11 @@ def main(n_side: int):
            "flux_nnz": int(data[pp.DISCRETIZATION_MATRICES]["flow"]["flux"].nnz),
            "p_norm": float(np.linalg.norm(p)), "peak_rss_gb": rss_gb,
            "host_cores": os.cpu_count(), "porepy_from": os.path.dirname(pp.__file__),
-           "numpy": np.__version__}
+           "numpy": np.__version__, "num_subproblems": int(num_sub),
+           "threads_env": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS")}}
     print("RESULT " + json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 32)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 32, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+         float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)

@@ -1070,8 +1070,37 @@ def patch_targets(raw: dict, n_random: int = 6, seed: int = 3):
     return cells
 
 
+def reference_on_patches(patches, product: bool):
+    """The REFERENCE ITSELF (pp.Mpfa, python inverter) on patches [(lraw, K, lbc, eta)], in one subprocess
+    (tests/_reference_patch_script.py; the live tree in the build container, the byte-compiled archive on the GPU box).
+    Returns a list of {key: csr} or None where no reference is importable."""
+    import subprocess
+    import sys
+    import tempfile
+
+    import oracle
+
+    env = oracle.ref_env(prefer_archive=product)
+    if env is None:
+        return None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory(prefix="pfv_patches_") as d:
+        for i, (lraw, K, lbc, eta) in enumerate(patches):
+            np.savez(os.path.join(d, f"patch_{i:03d}.npz"), K=K, is_dir=lbc["is_dir"], is_neu=lbc["is_neu"], eta=eta,
+                     **{k: v for k, v in lraw.items() if isinstance(v, (np.ndarray, int, str))})
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "_reference_patch_script.py"), d], env=env,
+                           cwd="/tmp", capture_output=True, text=True, timeout=1500)
+        assert any(l.startswith("RESULT") for l in r.stdout.splitlines()), r.stderr[-2000:]
+        out = []
+        for i in range(len(patches)):
+            z = np.load(os.path.join(d, f"ref_{i:03d}.npz"))
+            out.append({k: sps_csr((z[k + "_data"], z[k + "_indices"], z[k + "_indptr"]), shape=tuple(z[k + "_shape"]))
+                        for k in ALL_KEYS})
+    return out
+
+
 def grid_patch_parity(lib, raw, Kvals, flags, eta, bv=None, src=None, targets=None, rtol=1e-13, check_solve=True,
-                      generic_pattern=False):
+                      generic_pattern=False, reference: bool = False):
     """Rows of ALL SIX device matrices and of A = div flux of one full-size problem (raw grid, permeability
     (3,3,Nc), per-face flags 1 = Dirichlet / 2 = Neumann) against the oracle run on patches cut out of it.
     A face row only involves the interaction regions of the face's nodes, so on a patch = some cells + one
@@ -1099,6 +1128,7 @@ def grid_patch_parity(lib, raw, Kvals, flags, eta, bv=None, src=None, targets=No
     targets = patch_targets(raw) if targets is None else targets
     checked, worst = 0, {}
     patterns_checked = 0
+    ref_inputs, ref_rows = [], []  # reference = True: the patches and the device rows, compared after the loop
     ex = lambda idx: (nd * np.asarray(idx)[:, None] + np.arange(nd)[None, :]).ravel()  # noqa: E731
     for c0 in targets:
         inner = cutter.cells_around(c0)
@@ -1115,12 +1145,17 @@ def grid_patch_parity(lib, raw, Kvals, flags, eta, bv=None, src=None, targets=No
         fmap[face_gid] = np.arange(face_gid.size)
         vmap = np.full(nd * nc, -1)
         vmap[ex(cell_gid)] = np.arange(nd * cell_gid.size)
+        if reference:
+            ref_inputs.append((lraw, np.ascontiguousarray(Kvals[:, :, cell_gid]), lbc, eta))
+            ref_rows.append({"lfaces": lfaces, "interior": cutter.sides[gfaces] == 2})
         for k in ALL_KEYS:
             m = {"flux": cmap, "bound_pressure_cell": cmap, "bound_flux": fmap, "bound_pressure_face": fmap,
                  "vector_source": vmap, "bound_pressure_vector_source": vmap}[k]
             G = ctx.matrix_rows(WHICH[k], gfaces).tocoo()
             assert np.all(m[G.col] >= 0), (k, c0)  # the global rows stay inside the patch
             Gl = sps_csr((G.data, (G.row, m[G.col])), shape=(gfaces.size, ora[k].shape[1]))
+            if reference:
+                ref_rows[-1][k] = Gl.copy()
             err = rel_max_err(Gl, ora[k][lfaces])
             worst[k] = max(worst.get(k, 0.0), err)
             assert err < TOL, (k, c0, err)
@@ -1153,6 +1188,36 @@ def grid_patch_parity(lib, raw, Kvals, flags, eta, bv=None, src=None, targets=No
         checked += lfaces.size
     out.update({"rows_checked": checked, "patches": len(targets), "worst_rel_err": worst,
                 "patterns_bit_exact": patterns_checked})
+    if reference:
+        # ---- the same rows against the REFERENCE ITSELF run on the same patches (same geometry arrays, same tensors)
+        is_product = bool(lib.pfv_is_device_build())
+        refs = reference_on_patches(ref_inputs, product=is_product)
+        out["reference_patches"] = 0 if refs is None else len(refs)
+        if refs is not None:
+            worst_ref, exact = {}, 0
+            for rows, ref in zip(ref_rows, refs):
+                for k in ALL_KEYS:
+                    Rl = sps_csr(ref[k][rows["lfaces"]])
+                    Gl = rows[k]
+                    err = rel_max_err(Gl, Rl)
+                    worst_ref[k] = max(worst_ref.get(k, 0.0), err)
+                    assert err < TOL, ("reference", k, err)
+                    # pattern: what the reference stores is stored here (north_star parity metric 1); on the generic
+                    # grid the stencils of the cell-column matrices are identical, index for index
+                    Rl.sort_indices()
+                    Gl.sort_indices()
+                    stored = lambda m: sps_csr((np.ones(m.indices.size, np.int8), m.indices, m.indptr), shape=m.shape)  # noqa: E731
+                    D = stored(Rl) - stored(Gl)
+                    assert D.nnz == 0 or D.max() <= 0, ("the reference stores an entry the device pattern lacks", k)
+                    if generic_pattern and k in ("flux", "vector_source"):
+                        rows_of = np.repeat(np.arange(Gl.shape[0]), np.diff(Gl.indptr))
+                        keep = rows["interior"][rows_of]
+                        rows_ref = np.repeat(np.arange(Rl.shape[0]), np.diff(Rl.indptr))
+                        keep_ref = rows["interior"][rows_ref]
+                        assert np.array_equal(Gl.indices[keep], Rl.indices[keep_ref]), ("pattern vs reference", k)
+                        exact += 1
+            out["worst_rel_err_vs_reference"] = worst_ref
+            out["patterns_bit_exact_vs_reference"] = exact
     return out
 
 
@@ -1164,7 +1229,7 @@ def bench_grid_patch_parity(lib, n_side: int = 69, n_random: int = 6):
 
     lp, Kvals, flags, bv, src, eta = bench.make_slab_problem(n_side, 0, 1)
     return grid_patch_parity(lib, lp.raw, Kvals, flags, eta, bv, src, patch_targets(lp.raw, n_random),
-                             generic_pattern=True)
+                             generic_pattern=True, reference=True)
 
 
 def config_c2_patch_parity(lib, n_side: int = 32, n_random: int = 6):
@@ -1181,7 +1246,10 @@ def config_c2_patch_parity(lib, n_side: int = 32, n_random: int = 6):
     flags[bf] = 1
     bv = np.zeros(nf)
     bv[bf] = g.face_centers[0, bf]
-    out = grid_patch_parity(lib, raw, Kvals, flags, 1.0 / 3.0, bv, np.zeros(nc), patch_targets(raw, n_random))
+    # reference = True: on this lattice the reference drops exact zeros -- its stored pattern must be a subset of the
+    # structural stencil, the values agree to 1e-10
+    out = grid_patch_parity(lib, raw, Kvals, flags, 1.0 / 3.0, bv, np.zeros(nc), patch_targets(raw, n_random),
+                            reference=True)
     out["max_abs_error_vs_exact_linear_field"] = float(np.max(np.abs(out["x"] - g.cell_centers[0])))
     return out
 

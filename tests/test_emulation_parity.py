@@ -279,8 +279,14 @@ def test_bench_grid_patch_parity_machinery_small(lib):
     out = P.bench_grid_patch_parity(lib, 5, n_random=2)
     assert out["patches"] == 16 and out["rows_checked"] > 200
     assert out["true_rel_residual"] < 1e-12
+    # the same rows against the reference itself (pp.Mpfa on the same patches), where it is importable
+    if out["reference_patches"]:
+        assert out["reference_patches"] == 16 and out["patterns_bit_exact_vs_reference"] == 32
+        assert max(out["worst_rel_err_vs_reference"].values()) < 1e-10
     out = P.config_c2_patch_parity(lib, 4, n_random=2)
     assert out["max_abs_error_vs_exact_linear_field"] < 1e-10
+    if out["reference_patches"]:
+        assert max(out["worst_rel_err_vs_reference"].values()) < 1e-10
 
 
 @pytest.mark.parametrize("with_vs", [True, False])

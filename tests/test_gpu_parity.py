@@ -301,6 +301,10 @@ def test_timed_bench_grid_all_matrices_on_patches(lib):
     out = P.bench_grid_patch_parity(lib, 69)
     assert out["patches"] >= 20 and out["rows_checked"] > 1500
     assert out["true_rel_residual"] < 1e-12, out["true_rel_residual"]
+    # ... and against the REFERENCE ITSELF: pp.Mpfa (byte-compiled archive oracle/_ref) run on the same 20 patches
+    assert out["reference_patches"] == out["patches"], "reference archive oracle/_ref/porepy_ref.zip missing on the GPU box"
+    assert max(out["worst_rel_err_vs_reference"].values()) < 1e-10
+    assert out["patterns_bit_exact_vs_reference"] == 2 * out["patches"]  # flux + vector_source stencils, index for index
 
 
 def test_config_c2_all_matrices_on_patches(lib):
@@ -308,6 +312,10 @@ def test_config_c2_all_matrices_on_patches(lib):
     out = P.config_c2_patch_parity(lib, 32)
     assert out["patches"] >= 20 and out["rows_checked"] > 1500
     assert out["max_abs_error_vs_exact_linear_field"] < 1e-10, out["max_abs_error_vs_exact_linear_field"]
+    # the reference on the same patches: values to 1e-10, its stored pattern (exact zeros dropped on this lattice) a
+    # subset of the structural stencil
+    assert out["reference_patches"] == out["patches"]
+    assert max(out["worst_rel_err_vs_reference"].values()) < 1e-10
 
 
 @pytest.mark.parametrize("name", ["tpfaad_cart2d_4x3", "tpfaad_tri2d_3x3", "tpfaad_tet3d_2x2x2", "tpfaad_cart2d_tilted_3x2"])
