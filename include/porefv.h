@@ -70,7 +70,7 @@ enum { PFV_SOLVE_CG = 0, PFV_SOLVE_BICGSTAB = 1, PFV_SOLVE_GMRES = 2 };
 /* preconditioners of pfv_solve: Jacobi (default), or one V(1,1) cycle of a plain-aggregation
  * algebraic multigrid built on the device from the assembled matrix (pairwise matching on the
  * strength graph, piecewise-constant prolongation, Galerkin coarse matrices) */
-enum { PFV_PRECOND_JACOBI = 0, PFV_PRECOND_AMG = 1 };
+enum { PFV_PRECOND_JACOBI = 0, PFV_PRECOND_AMG = 1, PFV_PRECOND_BLOCK = 2 };
 
 /* flags for pfv_mpfa_discretize */
 enum {
@@ -305,6 +305,17 @@ pfv_status pfv_set_vectors_on_device(pfv_ctx* h, int on);
 
 /* Select the preconditioner of the following pfv_solve calls on this handle. */
 pfv_status pfv_set_preconditioner(pfv_ctx* h, int kind);
+
+/* Block preconditioner (PFV_PRECOND_BLOCK) for the coupled Jacobians of mixed-dimensional / multi-physics models
+ * that the reference solves directly (models/solution_strategy.py:830-884; mortar coupling
+ * models/constitutive_laws.py:987-1000): the unknowns of the system given to pfv_set_system are grouped in
+ * n_blocks contiguous blocks [block_ptr[k], block_ptr[k+1]) -- one per (variable, subdomain or interface) -- and
+ * the preconditioner is the block lower-triangular part of A, every diagonal block solved by one cycle of its own
+ * aggregation-AMG hierarchy (blocks of at most 1024 rows: exactly, by their dense inverse).  gauss_seidel = 0: block
+ * Jacobi.  Every diagonal entry must be non-zero: systems whose equations are ordered differently from their
+ * unknowns are row-permuted first (host side: porepy_amd.solvers.match_rows).  Selects PFV_PRECOND_BLOCK; the
+ * blocks are (re)built by the next pfv_solve. */
+pfv_status pfv_set_block_preconditioner(pfv_ctx* h, int64_t n_blocks, const int64_t* block_ptr, int gauss_seidel);
 
 /* Jacobi-preconditioned Krylov solve of A x = b on the device (stand-in for
  * SolutionStrategy.solve_linear_system, models/solution_strategy.py:830-884).

@@ -42,7 +42,7 @@ EXPORTS = [
     "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
     "pfv_rccl_unique_id", "pfv_rccl_comm_create", "pfv_rccl_set_halo_plan", "pfv_rccl_hooks", "pfv_rccl_stats",
     "pfv_rccl_last_error", "pfv_rccl_comm_destroy", "pfv_mpfa_ad_flux_system", "pfv_host_alloc", "pfv_host_free",
-    "pfv_mpsa_set_subface_eta", "pfv_mpsa_set_reconstruction_eta", "pfv_get_stats_n",
+    "pfv_mpsa_set_subface_eta", "pfv_mpsa_set_reconstruction_eta", "pfv_get_stats_n", "pfv_set_block_preconditioner",
 ]
 
 
@@ -198,6 +198,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_sync.restype = C.c_int
     lib.pfv_get_stats.argtypes = [_h, C.POINTER(Stats)]
     lib.pfv_get_stats.restype = C.c_int
+    lib.pfv_set_block_preconditioner.argtypes = [_h, C.c_int64, C.POINTER(C.c_int64), C.c_int]
+    lib.pfv_set_block_preconditioner.restype = C.c_int
     lib.pfv_get_stats_n.argtypes = [_h, C.c_void_p, C.c_size_t]
     lib.pfv_get_stats_n.restype = C.c_int
     lib.pfv_time_kernel.argtypes = [_h, C.c_int, C.c_int, _dp]
@@ -836,7 +838,7 @@ class Context:
                      raise_on_fail=True, restart=0, precond="jacobi"):
         """``solve`` writing the solution into the device buffer at ``x_ptr`` (n doubles); returns info."""
         code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB, "gmres": SOLVE_GMRES}[method]
-        self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1}[precond]))
+        self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1, "block": 2}[precond]))
         info = SolveInfo()
         self._dev(True)
         try:
@@ -867,7 +869,7 @@ class Context:
         """Solve the system assembled last (flow: n = Nc; mechanics: pass n = nd * Nc).
         ``restart``: GMRES cycle length (0 = 30); ``precond``: "jacobi" or "amg"."""
         code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB, "gmres": SOLVE_GMRES}[method]
-        self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1}[precond]))
+        self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1, "block": 2}[precond]))
         x = pinned_pool(self.lib).empty(self._active_n(n), np.float64)
         x0a = None if x0 is None else _f64(x0)
         if x0a is not None and x0a.shape != x.shape:
@@ -897,6 +899,13 @@ class Context:
         bb = _f64(b)
         self._check(self.lib.pfv_set_system(self._h, n, _ptr(ip, _ip), _ptr(ix, _ip), _ptr(dv, _dp), _ptr(bb, _dp)))
         self._user_n = n
+
+    def set_block_preconditioner(self, block_ptr, gauss_seidel: bool = True):
+        """Contiguous blocks [block_ptr[k], block_ptr[k+1]) of the system of ``set_system``: the following solves with
+        ``precond="block"`` use the block lower-triangular preconditioner (pfv_set_block_preconditioner)."""
+        bp = np.ascontiguousarray(block_ptr, dtype=np.int64)
+        self._check(self.lib.pfv_set_block_preconditioner(self._h, bp.size - 1, bp.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                          1 if gauss_seidel else 0))
 
     def stats(self) -> dict:
         s = Stats()
@@ -949,7 +958,7 @@ class Context:
         enqueue work on the handle's stream.  ``work_ptr``: 2 n_local + 8 doubles of device memory (the
         addresses the hooks see point into it), ``x_ptr``: n_own doubles for the solution."""
         code = {"cg": SOLVE_CG, "bicgstab": SOLVE_BICGSTAB}[method]
-        self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1}[precond]))
+        self._check(self.lib.pfv_set_preconditioner(self._h, {"jacobi": 0, "amg": 1, "block": 2}[precond]))
         failure = []
 
         def _halo(_user, d_x, _stream):

@@ -78,7 +78,8 @@ struct LinSys {
   const WinCsr* win = nullptr;  // optional (pfv_solve builds it)
 };
 
-struct Amg;  // amg.inc
+struct Amg;      // amg.inc
+struct BlockPc;  // amg.inc
 
 struct pfv_ctx_impl {
   MemPool pool;     // first member: destroyed last, after every buffer has been handed back
@@ -253,6 +254,7 @@ struct pfv_ctx_impl {
   unsigned long long pat_A_checksum = 0;   // checksum of pat_A's index arrays left by the symbolic phase (0: none)
   unsigned long long win_sys_checksum = 0; // ... of the pattern win_sys was built for (0: unknown)
   unsigned long long symbolic_epoch = 0;  // bumped by every symbolic phase: saved AMG aggregates die with it
+  std::unique_ptr<BlockPc> block_pc;  // pfv_set_block_preconditioner
   std::unique_ptr<Amg> amg_block;    // pfv_amg_setup: hierarchy of the leading block (sharded solves)
   CsrPattern pat_block;
   Buf<double> val_block;

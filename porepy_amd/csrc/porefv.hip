@@ -646,6 +646,7 @@ pfv_status pfv_mpfa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     if (!h->have_system) {
       pfv::assemble_system(*h);
       if (h->amg) h->amg->valid = false;
+      if (h->block_pc) h->block_pc->for_val = nullptr;
       if (h->amg_block) h->amg_block->valid = false;
       h->perm_for_val = nullptr;
       // windows built for this very pattern by the discretize call are kept
@@ -703,6 +704,7 @@ pfv_status pfv_mpfa_ad_flux_system(pfv_ctx* h, const double* p, const double* dk
     pfv::be_sync(s);
     h->have_system = false;  // PFV_MAT_SYSTEM now holds J, not div flux: pfv_mpfa_assemble rebuilds it
     if (h->amg) h->amg->valid = false;
+      if (h->block_pc) h->block_pc->for_val = nullptr;
     if (h->amg_block) h->amg_block->valid = false;
     h->perm_for_val = nullptr;
     h->win_for = h->win_rows_for = nullptr;
@@ -1077,6 +1079,7 @@ pfv_status pfv_mpsa_assemble(pfv_ctx* h, const double* bc_values, const double* 
     if (!h->have_mech_system) {
       pfv::mpsa_assemble_system(*h);
       if (h->amg) h->amg->valid = false;
+      if (h->block_pc) h->block_pc->for_val = nullptr;
       if (h->amg_block) h->amg_block->valid = false;
       h->perm_for_val = nullptr;
       h->win_for = h->win_rows_for = nullptr;
@@ -1305,6 +1308,7 @@ pfv_status pfv_set_system(pfv_ctx* h, int64_t n, const int32_t* indptr, const in
     h->active.n = n;
     h->active_bs = 1;
     if (h->amg) h->amg->valid = false;
+      if (h->block_pc) h->block_pc->for_val = nullptr;
     if (h->amg_block) h->amg_block->valid = false;
     h->perm_for_val = nullptr;
     h->win_for = h->win_rows_for = nullptr;
@@ -1453,8 +1457,21 @@ pfv_status pfv_amg_apply_device(pfv_ctx* h, const double* d_r, double* d_z) {
 
 pfv_status pfv_set_preconditioner(pfv_ctx* h, int kind) {
   return guarded(h, [&] {
-    require(kind == PFV_PRECOND_JACOBI || kind == PFV_PRECOND_AMG, "unknown preconditioner");
+    require(kind == PFV_PRECOND_JACOBI || kind == PFV_PRECOND_AMG || (kind == PFV_PRECOND_BLOCK && h->block_pc),
+            "unknown preconditioner (PFV_PRECOND_BLOCK: pfv_set_block_preconditioner first)");
     h->precond = kind;
+  });
+}
+
+pfv_status pfv_set_block_preconditioner(pfv_ctx* h, int64_t n_blocks, const int64_t* block_ptr, int gauss_seidel) {
+  return guarded(h, [&] {
+    require(n_blocks >= 1 && block_ptr != nullptr && block_ptr[0] == 0, "bad block layout");
+    for (int64_t k = 0; k < n_blocks; ++k) require(block_ptr[k + 1] > block_ptr[k], "blocks must be non-empty and ascending");
+    if (!h->block_pc) h->block_pc = std::make_unique<pfv::BlockPc>();
+    h->block_pc->ptr.assign(block_ptr, block_ptr + n_blocks + 1);
+    h->block_pc->gs = gauss_seidel != 0;
+    h->block_pc->for_val = nullptr;
+    h->precond = PFV_PRECOND_BLOCK;
   });
 }
 
@@ -1475,7 +1492,8 @@ static pfv::LinSys solver_system(pfv_ctx* h, bool& permuted) {
       pfv::permute_matrix(*h, sys, bs);
       h->perm_for_val = sys.val;
       h->win_for = h->win_rows_for = nullptr;
-      if (h->amg) h->amg->valid = false;  // (the copy's buffers are shared by the flow and mechanics systems)
+      if (h->amg) h->amg->valid = false;
+      if (h->block_pc) h->block_pc->for_val = nullptr;  // (the copy's buffers are shared by the flow and mechanics systems)
     }
     pfv::permute_vector(*h, sys.n, bs, sys.rhs, h->rhs_perm.ensure(sys.n), true);
     sys.P = &h->pat_perm;
@@ -1536,6 +1554,18 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
         h->stats.amg_filter_theta = h->amg->filter_level0 ? h->amg->filter_theta : 0.0;
       }
       M.amg = h->amg.get();
+      Mp = &M;
+    } else if (h->precond == PFV_PRECOND_BLOCK) {
+      require(h->block_pc && !permuted, "pfv_set_block_preconditioner first (user systems only)");
+      require(h->block_pc->ptr.back() == (int64_t)n, "the block layout does not cover the system");
+      if (h->block_pc->for_val != sys.val) {
+        pfv::blockpc_setup(*h, *h->block_pc, *sys.P, sys.val);
+        h->stats.amg_setup_ms = h->block_pc->setup_ms;
+      }
+      M.blocks = h->block_pc.get();
+      M.P = sys.P;
+      M.val = sys.val;
+      M.diag = sys.diag;
       Mp = &M;
     }
     res = method == PFV_SOLVE_GMRES

@@ -8,9 +8,15 @@ them to the Jacobi-preconditioned Krylov solvers behind ``pfv_set_system`` / ``p
     params = {"linear_solver": "hip_bicgstab", ...}      # or "hip_gmres", "hip_cg"
     params["hip_solver_options"] = {"precond": "amg", "rtol": 1e-12}   # optional
 
-Any other ``linear_solver`` value falls through to the reference implementation.  Systems with
-zero diagonal entries (saddle-point blocks of mixed-dimensional models) are refused by the
-library, not solved badly.
+Any other ``linear_solver`` value falls through to the reference implementation.
+
+Coupled Jacobians of mixed-dimensional / multi-physics models (mortar fluxes, several variables per cell: the
+systems the reference hands to a direct solver) go through :func:`solve_block_system`: the rows are first paired with
+the unknowns by a maximum-product matching (the equations of such a model are ordered differently from its unknowns:
+most diagonal entries are structurally zero), the unknowns grouped in one block per (variable, subdomain / interface),
+and GMRES runs on the device with the block lower-triangular preconditioner of ``pfv_set_block_preconditioner`` --
+every diagonal block solved by its own AMG hierarchy (small blocks exactly).  ``HipLinearSolver`` takes this path
+with ``hip_solver_options = {"precond": "block"}``, the blocks read off the model's ``equation_system``.
 """
 from __future__ import annotations
 
@@ -38,6 +44,119 @@ def solve_csr(A, b, method: str = "bicgstab", rtol: float = 1e-12, maxit: int = 
     return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, restart=restart, n=A.shape[0], precond=precond)
 
 
+def match_rows(A):
+    """Row permutation ``perm`` such that ``A[perm]`` has a zero-free, large diagonal: a maximum-product perfect matching
+    of rows to columns (minimum-weight bipartite matching on ``-log |a_ij|``, scipy.sparse.csgraph).  The role of MC64
+    in direct solvers; host work, O(nnz log n).  Returns None when the diagonal is already structurally full and
+    dominant in every row that has one."""
+    import scipy.sparse as sps
+    from scipy.sparse.csgraph import min_weight_full_bipartite_matching
+
+    A = sps.csr_matrix(A)
+    n = A.shape[0]
+    d = np.abs(A.diagonal())
+    rowmax = np.maximum.reduceat(np.abs(A.data), A.indptr[:-1]) if A.nnz else np.zeros(n)
+    if np.all(d > 0) and np.all(d >= 0.1 * rowmax):
+        return None
+    B = sps.csr_matrix((np.abs(A.data), A.indices, A.indptr), shape=A.shape)
+    B.eliminate_zeros()
+    # weights > 0 for every stored entry: log(colmax / |a_ij|) + 1
+    colmax = np.asarray(abs(B).max(axis=0).todense()).ravel()
+    colmax[colmax == 0] = 1.0
+    W = B.copy()
+    W.data = np.log(colmax[B.indices] / B.data) + 1.0
+    rows, cols = min_weight_full_bipartite_matching(W)
+    perm = np.empty(n, dtype=np.int64)
+    perm[cols] = rows  # row perm[j] is matched to column j
+    return perm
+
+
+def solve_block_system(A, b, block_of, method: str = "gmres", rtol: float = 1e-12, maxit: int = 2000, restart: int = 60,
+                       device: int = 0, library=None, context: _lib.Context | None = None, gauss_seidel: bool = True,
+                       block_order=None, row_perm=None):
+    """Solve a coupled system whose unknown ``i`` belongs to block ``block_of[i]`` (one block per variable and
+    subdomain / interface) on the device: rows matched to unknowns (:func:`match_rows`), blocks made contiguous in
+    ``block_order`` (default: ascending block number), GMRES with the block lower-triangular preconditioner.  Returns
+    (x, info) with x in the caller's numbering; ``info["true_rel_residual"]`` is evaluated on the caller's system.
+    ``row_perm``: the pairing of equations with unknowns if the caller knows it (row ``row_perm[j]`` is the equation of
+    unknown ``j``; :func:`pair_equation_blocks` derives it from the block structure of a model) -- an entry-wise
+    matching can pair a pressure unknown with an energy equation whose advective term happens to be large, and the
+    diagonal block of that variable is then not the discretization of anything."""
+    import scipy.sparse as sps
+
+    A = sps.csr_matrix(A)
+    b = np.asarray(b, dtype=float)
+    n = A.shape[0]
+    block_of = np.asarray(block_of)
+    perm = match_rows(A) if row_perm is None else np.asarray(row_perm, dtype=np.int64)
+    if perm is not None and np.array_equal(perm, np.arange(n)):
+        perm = None
+    A1, b1 = (A, b) if perm is None else (A[perm], b[perm])
+    ids = list(np.unique(block_of)) if block_order is None else list(block_order)
+    rank = {int(k): i for i, k in enumerate(ids)}
+    key = np.array([rank[int(k)] for k in block_of])
+    order = np.argsort(key, kind="stable")
+    A2 = sps.csr_matrix(A1[order][:, order])
+    A2.sort_indices()
+    b2 = b1[order]
+    ptr = np.concatenate(([0], np.cumsum(np.bincount(key, minlength=len(ids))))).astype(np.int64)
+    ctx = context if context is not None else _lib.Context(device, library)
+    ctx.set_system(A2, b2)
+    ctx.set_block_preconditioner(ptr, gauss_seidel)
+    x2, info = ctx.solve(method=method, rtol=rtol, maxit=maxit, restart=restart, n=n, precond="block", raise_on_fail=False)
+    x = np.empty(n)
+    x[order] = np.atleast_1d(x2)
+    info = dict(info)
+    info["blocks"] = len(ids)
+    info["rows_matched"] = perm is not None
+    info["true_rel_residual"] = float(np.linalg.norm(b - A @ x) / max(np.linalg.norm(b), 1e-300))
+    return x, info
+
+
+def pair_equation_blocks(A, row_blocks, col_blocks):
+    """Pair equation blocks with variable blocks of a coupled Jacobian.  ``row_blocks`` / ``col_blocks``: lists of
+    ``(group, indices)`` -- group = the grid the equation / variable lives on; blocks of one group with equal sizes are
+    candidates for each other (mass balance and energy balance against pressure and temperature of the same
+    subdomain).  Within a group the assignment maximises the mean of log(|a_ii| / row maximum) of the candidate
+    sub-block's diagonal -- how dominant the entry of the block's own unknown is in each of its equations.  Returns
+    ``row_perm`` (see :func:`solve_block_system`)."""
+    import itertools
+
+    import scipy.sparse as sps
+
+    A = sps.csr_matrix(A)
+    n = A.shape[0]
+    rowmax = np.maximum.reduceat(np.abs(A.data), A.indptr[:-1])
+    rowmax[rowmax == 0] = 1.0
+    perm = np.full(n, -1, dtype=np.int64)
+    groups = {}
+    for g, idx in row_blocks:
+        groups.setdefault(g, ([], []))[0].append(np.asarray(idx))
+    for g, idx in col_blocks:
+        groups.setdefault(g, ([], []))[1].append(np.asarray(idx))
+    for g, (rows, cols) in groups.items():
+        if len(rows) != len(cols):
+            raise ValueError(f"group {g!r}: {len(rows)} equation blocks for {len(cols)} variable blocks")
+        m = len(rows)
+        W = np.full((m, m), -1e6)
+        for i, r in enumerate(rows):
+            for j, c in enumerate(cols):
+                if r.size == c.size:
+                    d = np.abs(np.asarray(A[r, c]).ravel())
+                    W[i, j] = float(np.mean(np.log(np.maximum(d, 1e-300) / rowmax[r]))) if np.all(d > 0) else -1e5
+        best = max(itertools.permutations(range(m)), key=lambda p: sum(W[i, p[i]] for i in range(m))) if m <= 6 else None
+        if best is None:
+            from scipy.optimize import linear_sum_assignment
+
+            ri, ci = linear_sum_assignment(-W)
+            best = tuple(ci[np.argsort(ri)])
+        for i, r in enumerate(rows):
+            perm[cols[best[i]]] = r
+    if np.any(perm < 0) or np.unique(perm).size != n:
+        raise ValueError("the blocks do not cover the system")
+    return perm
+
+
 class HipLinearSolver:
     """Mixin for PorePy models (put it before the model class in the bases)."""
 
@@ -60,6 +179,19 @@ class HipLinearSolver:
         opts = self.params.get("hip_solver_options", {})
         if getattr(self, "_hip_solver_context", None) is None:
             self._hip_solver_context = _lib.Context(int(opts.get("device", 0)), self.hip_library)
+        if str(opts.get("precond", "jacobi")) == "block":
+            block_of, row_perm = self._hip_blocks(opts)
+            x, info = solve_block_system(A, b, block_of, method=_METHODS[solver],
+                                         rtol=float(opts.get("rtol", 1e-12)), maxit=int(opts.get("maxit", 2000)),
+                                         restart=int(opts.get("restart", 60)), context=self._hip_solver_context,
+                                         gauss_seidel=bool(opts.get("gauss_seidel", True)), row_perm=row_perm)
+            if not info["converged"]:
+                raise RuntimeError(f"hip block solver did not converge: {info}")
+            self.hip_solver_info = info
+            x = np.atleast_1d(x)
+            if self._apply_schur_complement_reduction():
+                x = self.equation_system.expand_schur_complement_solution(x)
+            return x
         x, info = solve_csr(A, b, method=_METHODS[solver], rtol=float(opts.get("rtol", 1e-12)),
                             maxit=int(opts.get("maxit", 50000)), restart=int(opts.get("restart", 0)),
                             context=self._hip_solver_context, precond=str(opts.get("precond", "jacobi")))
@@ -68,3 +200,49 @@ class HipLinearSolver:
         if self._apply_schur_complement_reduction():
             x = self.equation_system.expand_schur_complement_solution(x)
         return x
+
+    def _hip_blocks(self, opts):
+        """``(block_of, row_perm)`` for ``self.linear_system``.  block_of: one block per (variable, grid) of the model's
+        ``equation_system`` (numerics/ad/equation_system.py: every md-variable occupies contiguous dofs on each of its
+        grids), cell variables first -- by ``opts["variable_order"]`` if given, else pressure-like names first -- then
+        the interface variables.  row_perm: the model's equation blocks (``assembled_equation_indices``, split by the
+        grids of their image space) paired with the variable blocks of the same grid (:func:`pair_equation_blocks`);
+        None (entry-wise matching) where the model does not expose that structure, e.g. after a Schur reduction."""
+        es = self.equation_system
+        A = self.linear_system[0]
+        n = A.shape[0]
+        block = np.full(n, -1, dtype=np.int64)
+        wanted = list(opts.get("variable_order", []))
+
+        def rank(var):
+            name = var.name
+            if name in wanted:
+                return (0, wanted.index(name))
+            is_intf = "interface" in name or hasattr(var.domain, "mortar_grid") or not hasattr(var.domain, "cell_faces")
+            return (2 if is_intf else 1, 0 if "pressure" in name else 1)
+
+        variables = sorted(es.variables, key=lambda v: (rank(v), v.name, -getattr(v.domain, "dim", 0), getattr(v.domain, "id", 0)))
+        k = 0
+        col_blocks = []
+        for var in variables:
+            dofs = np.asarray(es.dofs_of([var]))
+            if dofs.size and dofs.max() < n:
+                block[dofs] = k
+                col_blocks.append((id(var.domain), dofs))
+                k += 1
+        if np.any(block < 0):
+            block[block < 0] = k  # (unknowns outside the variable list: one block)
+            return block, None
+        row_perm = None
+        try:
+            row_blocks = []
+            for name, rows in es.assembled_equation_indices.items():
+                rows = np.asarray(rows)
+                for grid, loc in es._equation_image_space_composition[name].items():
+                    loc = np.asarray(loc)
+                    if loc.size:
+                        row_blocks.append((id(grid), rows[loc]))
+            row_perm = pair_equation_blocks(A, row_blocks, col_blocks)
+        except Exception:  # noqa: BLE001 - structure not exposed: fall back to the entry-wise matching
+            row_perm = None
+        return block, row_perm

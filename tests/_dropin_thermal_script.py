@@ -66,23 +66,40 @@ class Model(Geometry, BCs, MassAndEnergyBalance):
     pass
 
 
-def run():
+class HipSolveModel(pa.HipLinearSolver, Model):
+    hip_library = P.dropin_library()
+
+
+def run(cls=Model, linear_solver="scipy_sparse", opts=None):
     solid = pp.SolidConstants(permeability=0.5, thermal_conductivity=2.0, porosity=0.2, specific_heat_capacity=1.5,
                               normal_permeability=5.0, residual_aperture=1e-1)
     fluid = pp.FluidComponent(thermal_conductivity=0.6, specific_heat_capacity=2.0, compressibility=1e-2,
                               thermal_expansion=1e-3, viscosity=1.0)
-    params = {"times_to_export": [], "linear_solver": "scipy_sparse", "darcy_flux_discretization": "mpfa",
+    params = {"times_to_export": [], "linear_solver": linear_solver, "darcy_flux_discretization": "mpfa",
               "fourier_flux_discretization": "mpfa",
               "material_constants": {"solid": solid, "fluid": fluid},
               "time_manager": pp.TimeManager(schedule=[0.0, 0.2], dt_init=0.1, constant_dt=True),
               "max_iterations": 20, "nl_convergence_tol": 1e-10, "nl_convergence_tol_res": 1e-10}
-    m = Model(params)
+    if opts is not None:
+        params["hip_solver_options"] = opts
+    m = cls(params)
+    solves = []
+    if cls is not Model:
+        inner = m.solve_linear_system
+
+        def recording():
+            x = inner()
+            solves.append(dict(m.hip_solver_info))
+            return x
+
+        m.solve_linear_system = recording
     pp.run_time_dependent_model(m, params)
     x = m.equation_system.get_variable_values(time_step_index=0)
     A, b = m.linear_system
     names = sorted({v.name for v in m.equation_system.variables})
     return {"x": np.asarray(x), "A": A.copy(), "names": names, "dims": sorted({sd.dim for sd in m.mdg.subdomains()}, reverse=True),
-            "n_sub": len(m.mdg.subdomains()), "n_intf": len(m.mdg.interfaces()),
+            "n_sub": len(m.mdg.subdomains()), "n_intf": len(m.mdg.interfaces()), "solves": solves,
+            "blocks": m._hip_blocks({}) if cls is not Model else None,
             "T": np.asarray(m.equation_system.get_variable_values([m.temperature_variable], time_step_index=0)),
             "p": np.asarray(m.equation_system.get_variable_values([m.pressure_variable], time_step_index=0))}
 
@@ -102,8 +119,16 @@ def counting(self, sd, data):
 HipMpfa.discretize = counting
 pp.Mpfa = HipMpfa
 ours = run()
+# ... and with the linear systems of every Newton iteration solved on the device as well: GMRES with the block
+# lower-triangular preconditioner (rows matched to unknowns, one block per variable and subdomain / interface)
+both = run(HipSolveModel, "hip_gmres", {"precond": "block", "rtol": 1e-13, "restart": 80})
 nrm = np.linalg.norm(ref["x"])
 out = {
+    "x_rel_err_hip_solver": float(np.linalg.norm(both["x"] - ref["x"]) / nrm),
+    "hip_linear_solves": len(both["solves"]),
+    "hip_solver_max_iterations": int(max(s_["iterations"] for s_ in both["solves"])),
+    "hip_solver_blocks": int(both["solves"][0]["blocks"]), "hip_rows_matched": bool(both["solves"][0]["rows_matched"]),
+    "hip_solver_worst_true_residual": float(max(s_["true_rel_residual"] for s_ in both["solves"])),
     "variables": ref["names"], "dims": ref["dims"], "subdomains": ref["n_sub"], "interfaces": ref["n_intf"],
     "dofs": int(ref["x"].size), "device_calls": calls,
     "x_rel_err": float(np.linalg.norm(ours["x"] - ref["x"]) / nrm),
@@ -119,6 +144,6 @@ if "--save" in __import__("sys").argv:
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "md_thermal_jacobian_box_2fractures.npz")
     # right-hand side of a known answer (the converged state itself: the last Newton residual is round-off)
     np.savez_compressed(path, data=A.data, indices=A.indices, indptr=A.indptr, shape=np.array(A.shape),
-                        b=A @ ref["x"], x=ref["x"])
+                        b=A @ ref["x"], x=ref["x"], block_of=both["blocks"][0], row_perm=both["blocks"][1])
 out["library"] = str(P.dropin_library()._name)
 print("RESULT " + json.dumps(out))

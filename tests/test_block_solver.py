@@ -1,0 +1,24 @@
+"""Block-preconditioned device solve of coupled Jacobians (pfv_set_block_preconditioner):
+CPU suite on the host-emulation build, GPU suite on libporefv_hip.so."""
+import pytest
+
+import porepy_amd as pa
+from tests import _block_solver_cases as B
+from tests import _parity as P
+
+LIBS = [pytest.param("emulation", id="emulation"), pytest.param("product", id="product", marks=pytest.mark.gpu)]
+
+
+def _lib(which):
+    return P.emulation_library() if which == "emulation" else pa._lib.product_library()
+
+
+@pytest.mark.parametrize("which", LIBS)
+def test_thermo_hydro_mixed_dimensional_jacobian_with_the_block_preconditioner(which):
+    out = B.thermo_hydro_jacobian(_lib(which))
+    assert out["gs"] <= 80
+
+
+@pytest.mark.parametrize("which", LIBS)
+def test_large_blocks_take_the_amg_cycle(which):
+    assert B.flow_blocks_with_amg(_lib(which)) < 40

@@ -107,6 +107,12 @@ def test_thermo_hydro_mixed_dimensional_model_with_rebound_mpfa(variant):
     assert c["flow:3"] >= 1 and c["flow:2"] >= 2 and c["fourier_discretization:3"] >= 1 and c["fourier_discretization:2"] >= 2
     assert out["T_range"][1] - out["T_range"][0] > 1.0 and out["p_range"][1] - out["p_range"][0] > 0.5  # a non-trivial state
     assert max(out["x_rel_err"], out["T_rel_err"], out["p_rel_err"], out["A_rel_err"]) < 1e-10
+    # the linear systems of the Newton iterations -- equations ordered differently from the unknowns (most diagonal
+    # entries structurally zero), mortar coupling: what the reference hands to a direct solver -- solved on the
+    # device: GMRES + block lower-triangular preconditioner (porepy_amd.solvers.solve_block_system)
+    assert out["hip_linear_solves"] >= 4 and out["hip_rows_matched"] and out["hip_solver_blocks"] >= 10
+    assert out["hip_solver_worst_true_residual"] < 1e-11
+    assert out["x_rel_err_hip_solver"] < 1e-10
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
