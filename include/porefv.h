@@ -497,6 +497,7 @@ pfv_status pfv_csr_transpose(pfv_ctx* h, const pfv_csr* A, pfv_csr** out);
 pfv_status pfv_csr_bmat(pfv_ctx* h, int nbr, int nbc, const pfv_csr* const* blocks, const int64_t* row_sizes,
                         const int64_t* col_sizes, pfv_csr** out);
 pfv_status pfv_csr_scale(pfv_csr* A, const double* row_scale, const double* col_scale);   /* in place; host arrays or NULL */
+pfv_status pfv_csr_divide(pfv_csr* A, double s);   /* in place: every value divided by s (scipy's A / s) */
 pfv_status pfv_csr_spmv(const pfv_csr* A, const double* x, double* y);                     /* host vectors */
 pfv_status pfv_csr_spmv_device(const pfv_csr* A, const double* d_x, double* d_y);
 pfv_status pfv_csr_info(const pfv_csr* A, int64_t* nrows, int64_t* ncols, int64_t* nnz);

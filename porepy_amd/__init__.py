@@ -13,8 +13,9 @@ from .mpfa import Mpfa, as_porepy_discretization, determine_eta
 from .mpsa import Mpsa, as_porepy_mpsa
 from .biot import Biot, as_porepy_biot
 from .partial import active_indices
-from .solvers import HipLinearSolver, solve_csr
-from .device_csr import DeviceCsr, block_diag, bmat, merged_matrix
+from .solvers import HipLinearSolver, solve_block_system, solve_csr
+from .device_csr import DeviceCsr, block_diag, bmat, merged_matrix, vstack
+from . import ad
 from .tpfa import DifferentiableTpfa, Tpfa, as_porepy_ad_tpfa_flux
 from .params import (DISCRETIZATION_MATRICES, PARAMETERS, BoundaryCondition, BoundaryConditionVectorial,
                      FourthOrderTensor, SecondOrderTensor, bc_flags, bc_to_raw, initialize_data)
@@ -24,5 +25,5 @@ __all__ = [
     "StructuredTetrahedralGrid", "TetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "grid_from_raw", "Mpfa",
     "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition", "Mpsa",
     "FourthOrderTensor", "BoundaryConditionVectorial",
-    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa", "DifferentiableTpfa", "as_porepy_ad_tpfa_flux", "Biot", "as_porepy_mpsa", "as_porepy_biot", "DeviceCsr", "block_diag", "bmat", "merged_matrix",
+    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa", "DifferentiableTpfa", "as_porepy_ad_tpfa_flux", "Biot", "as_porepy_mpsa", "as_porepy_biot", "DeviceCsr", "block_diag", "bmat", "merged_matrix", "vstack", "ad", "solve_block_system",
 ]

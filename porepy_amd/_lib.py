@@ -36,7 +36,7 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_setup_sharded", "pfv_amg_apply_device", "pfv_csr_from_host", "pfv_csr_from_matrix", "pfv_csr_block_diag", "pfv_csr_matmul", "pfv_csr_axpby", "pfv_csr_transpose", "pfv_csr_bmat", "pfv_csr_scale", "pfv_csr_spmv", "pfv_csr_spmv_device", "pfv_csr_info", "pfv_csr_get", "pfv_csr_set_system", "pfv_csr_free", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc", "pfv_mpsa_set_subface_bc",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_setup_sharded", "pfv_amg_apply_device", "pfv_csr_from_host", "pfv_csr_from_matrix", "pfv_csr_block_diag", "pfv_csr_matmul", "pfv_csr_axpby", "pfv_csr_transpose", "pfv_csr_bmat", "pfv_csr_scale", "pfv_csr_divide", "pfv_csr_spmv", "pfv_csr_spmv_device", "pfv_csr_info", "pfv_csr_get", "pfv_csr_set_system", "pfv_csr_free", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc", "pfv_mpsa_set_subface_bc",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
     "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces", "pfv_solve_sharded", "pfv_tpfa_transmissibility_ad",
     "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
@@ -154,6 +154,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_csr_transpose.argtypes = [_h, _h, C.POINTER(_h)]
     lib.pfv_csr_bmat.argtypes = [_h, C.c_int, C.c_int, C.POINTER(_h), _lp, _lp, C.POINTER(_h)]
     lib.pfv_csr_scale.argtypes = [_h, _dp, _dp]
+    lib.pfv_csr_divide.argtypes = [_h, C.c_double]
+    lib.pfv_csr_divide.restype = C.c_int
     lib.pfv_csr_spmv.argtypes = [_h, _dp, _dp]
     lib.pfv_csr_spmv_device.argtypes = [_h, C.c_void_p, C.c_void_p]
     lib.pfv_csr_info.argtypes = [_h, _lp, _lp, _lp]

@@ -10,9 +10,12 @@ discretization matrices of a handle without a host copy, combined with ``@``, ``
 a discretization matrix never crosses PCIe.  The results follow scipy's conventions bit for bit (sorted rows,
 products and sums accumulated in scipy's order, exact zeros dropped), which is how the tests pin them.
 
-The operator TREE (``pp.ad`` parsing, variables, time stepping) stays in the reference: its AD layer checks
-``isinstance(m, scipy.sparse.spmatrix)`` and would not accept a foreign matrix type; what is built here is the sparse
-algebra a device-side evaluation of that tree needs."""
+The operator TREE is walked by the reference's own parser (``numerics/ad/_ad_parser.py``): a ``DeviceCsr`` offers
+exactly what ``forward_mode.AdArray`` asks of its Jacobian -- ``shape``, ``astype``, row selection ``J[dofs]``,
+``sps.diags(v) * J`` (row scaling), ``J + K``, ``-J``, ``scalar * J``, ``M @ J`` for a scipy ``M`` -- so an ``AdArray``
+whose Jacobian lives on the device flows through the reference's operator arithmetic unchanged (``porepy_amd.ad``:
+``assemble_on_device``).  Operands that arrive as scipy matrices (divergences, projections, discretization matrices of
+an eager ``Mpfa``) are uploaded once and remembered while the host object lives."""
 from __future__ import annotations
 
 import ctypes as C
@@ -31,7 +34,10 @@ class DeviceCsr:
     def __init__(self, context: "_lib.Context", handle):
         self.ctx = context
         self._c = handle
-        context._csr_refs.append(weakref.ref(self))
+        refs = context._csr_refs
+        if len(refs) >= 64 and len(refs) % 64 == 0:  # drop the entries of matrices that are gone (temporaries of @, +)
+            refs[:] = [r for r in refs if r() is not None]
+        refs.append(weakref.ref(self))
 
     # ---- construction ------------------------------------------------------------------------------------------
     @classmethod
@@ -68,6 +74,18 @@ class DeviceCsr:
 
         if isinstance(m, DeviceCsr):
             return m
+        if not isinstance(m, LazyCsr):
+            # an operand that lives on the host (divergence, projection, eager discretization matrix): uploaded once,
+            # remembered while the host object is alive and unchanged in size
+            hit = _UPLOADS.get(id(m))
+            if hit is not None and hit[0]() is m and hit[1].ctx is context and hit[1]._c and hit[2] == (m.shape, m.nnz):
+                return hit[1]
+            d = cls.from_scipy(m, context)
+            try:
+                _UPLOADS[id(m)] = (weakref.ref(m, lambda _r, k=id(m): _UPLOADS.pop(k, None)), d, (m.shape, m.nnz))
+            except TypeError:
+                pass
+            return d
         if isinstance(m, LazyCsr) and not m.materialized and m._ctx is not None:
             if m._post is None:
                 return cls.from_discretization(m._ctx, m._which, context)
@@ -93,6 +111,32 @@ class DeviceCsr:
 
     ndim = 2
 
+    def astype(self, dtype):
+        """(values are always FP64)"""
+        return self
+
+    def __getitem__(self, key) -> "DeviceCsr":
+        """Row selection ``J[rows]`` (index array, boolean mask, slice or one index): the product with the selection
+        matrix, on the device -- how ``AdArray.__getitem__`` restricts a Jacobian to the dofs of a variable."""
+        import scipy.sparse as sps
+
+        n = self.shape[0]
+        if isinstance(key, tuple):
+            raise IndexError("only rows can be selected")
+        rows = np.arange(n)[key]
+        rows = np.atleast_1d(rows).astype(np.int64)
+        S = sps.csr_matrix((np.ones(rows.size), rows, np.arange(rows.size + 1)), shape=(rows.size, n))
+        return DeviceCsr.from_scipy(S, self.ctx) @ self
+
+    @staticmethod
+    def _diagonal_of(m):
+        """The diagonal of a scipy diagonal matrix (``sps.diags(v)``), or None."""
+        import scipy.sparse as sps
+
+        if sps.issparse(m) and m.format == "dia" and m.shape[0] == m.shape[1] and len(m.offsets) == 1 and m.offsets[0] == 0:
+            return np.asarray(m.diagonal(), dtype=np.float64)
+        return None
+
     # ---- algebra -----------------------------------------------------------------------------------------------
     def _binary(self, fn, *args):
         out = _lib._h()
@@ -100,8 +144,15 @@ class DeviceCsr:
         return DeviceCsr(self.ctx, out)
 
     def __matmul__(self, other):
+        import scipy.sparse as sps
+
         if isinstance(other, DeviceCsr):
             return self._binary(self.ctx.lib.pfv_csr_matmul, self._c, other._c)
+        if sps.issparse(other):
+            d = self._diagonal_of(other)
+            if d is not None:
+                return self.scaled(cols=d)
+            return self._binary(self.ctx.lib.pfv_csr_matmul, self._c, DeviceCsr.from_any(other, self.ctx)._c)
         x = np.asarray(other)
         if x.ndim != 1 or x.shape[0] != self.shape[1]:
             raise ValueError("DeviceCsr @ x expects a vector of matching length (or another DeviceCsr)")
@@ -120,11 +171,24 @@ class DeviceCsr:
         """alpha * self + beta * other."""
         return self._binary(self.ctx.lib.pfv_csr_axpby, float(alpha), self._c, float(beta), other._c)
 
+    def __rmatmul__(self, other):
+        """``M @ J`` for a scipy ``M`` (scipy's own ``@`` returns NotImplemented for a foreign right operand)."""
+        d = self._diagonal_of(other)
+        if d is not None:
+            return self.scaled(rows=d)
+        return DeviceCsr.from_any(other, self.ctx) @ self
+
     def __add__(self, other):
-        return self.axpby(1.0, other, 1.0)
+        return self.axpby(1.0, DeviceCsr.from_any(other, self.ctx), 1.0)
+
+    def __radd__(self, other):
+        return DeviceCsr.from_any(other, self.ctx).axpby(1.0, self, 1.0)
 
     def __sub__(self, other):
-        return self.axpby(1.0, other, -1.0)
+        return self.axpby(1.0, DeviceCsr.from_any(other, self.ctx), -1.0)
+
+    def __rsub__(self, other):
+        return DeviceCsr.from_any(other, self.ctx).axpby(1.0, self, -1.0)
 
     @property
     def T(self) -> "DeviceCsr":
@@ -149,11 +213,34 @@ class DeviceCsr:
         return out
 
     def __mul__(self, alpha):
+        """scalar * J; ``J * sps.diags(v)`` (column scaling, the old-style matrix product of scipy's ``*``).  Entries that
+        become exact zeros stay stored (scipy's scalar product keeps them too)."""
+        if np.isscalar(alpha):
+            return self.scaled(rows=np.full(self.shape[0], float(alpha)))
+        d = self._diagonal_of(alpha)
+        if d is not None:
+            return self.scaled(cols=d)
+        return NotImplemented
+
+    def __rmul__(self, alpha):
+        """scalar * J; ``sps.diags(v) * J`` (row scaling: ``AdArray._diagvec_mul_jac``)."""
+        if np.isscalar(alpha):
+            return self.scaled(rows=np.full(self.shape[0], float(alpha)))
+        d = self._diagonal_of(alpha)
+        if d is not None:
+            return self.scaled(rows=d)
+        import scipy.sparse as sps
+
+        if sps.issparse(alpha):
+            return self.__rmatmul__(alpha)
+        return NotImplemented
+
+    def __truediv__(self, alpha):
         if not np.isscalar(alpha):
             return NotImplemented
-        return self.scaled(rows=np.full(self.shape[0], float(alpha)))
-
-    __rmul__ = __mul__
+        out = block_diag([self])
+        self.ctx._check(self.ctx.lib.pfv_csr_divide(out._c, float(alpha)))
+        return out
 
     def __neg__(self):
         return self * -1.0
@@ -201,6 +288,14 @@ class DeviceCsr:
     def __repr__(self):
         r, c, z = self._info()
         return f"<DeviceCsr {r}x{c}, {z} stored entries, on device>"
+
+
+_UPLOADS: dict = {}  # id(host matrix) -> (weakref to it, its DeviceCsr, (shape, nnz)); see DeviceCsr.from_any
+
+
+def vstack(mats, context: "_lib.Context | None" = None) -> DeviceCsr:
+    """``scipy.sparse.vstack`` on the device (the rows of the equations of a model, one block per equation)."""
+    return bmat([[m] for m in mats], context)
 
 
 def block_diag(mats, context: "_lib.Context | None" = None) -> DeviceCsr:

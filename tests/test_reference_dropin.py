@@ -133,3 +133,22 @@ def test_merged_operator_parse_and_flux_products_on_the_device(variant):
     assert max(out["merged_rel_err"].values()) < 1e-10
     assert out["J_pp_rel_err"] < 1e-10 and out["J_pl_rel_err"] < 1e-10 and out["flux_rel_err"] < 1e-10
     assert out["J_pp_shape"] == [100, 100] and out["J_pl_nnz"] > 0
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_operator_trees_of_the_reference_evaluated_with_device_jacobians(variant):
+    """``EquationSystem.assemble`` (numerics/ad/equation_system.py:1579) against
+    ``porepy_amd.ad.assemble_on_device`` -- the reference's own parser (numerics/ad/_ad_parser.py) and ``AdArray``
+    arithmetic (numerics/ad/forward_mode.py) walking the model's operator trees from an identity whose Jacobian is a
+    ``DeviceCsr``: every Jacobian product, row scaling and sum of the tree runs on the device.  The mixed-dimensional
+    compressible flow model at a perturbed state: residual and Jacobian bit for bit; the thermo-hydro model (7
+    equations, upwinding, density and enthalpy functions): same pattern, values to the last bit or two."""
+    out = run_script("_dropin_adtree_script.py", variant, 600)
+    f = out["md_flow"]
+    assert f["dims"] == [3, 2, 1] and f["dofs"] == 180 and f["equations"] == 3
+    assert f["bit_identical"] is True and f["rhs_identical"] is True
+    assert out["newton_increment_rel_err"] < 1e-10 and out["newton_increment_iterations"] > 0
+    t = out["thermo_hydro"]
+    assert "error" not in t, t
+    assert t["dofs"] == 440 and t["equations"] == 7 and t["same_nonzero_pattern"] is True and t["rhs_identical"] is True
+    assert t["jac_rel_err"] < 1e-15
