@@ -335,6 +335,7 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
     pfv::Timer tm, tall;
     tall.start(s);
     bool node_done = false;
+    bool cells_deferred = false;  // part 2 of the symbolic phase (pattern of A) still to be built
     if (!h->have_topology || !h->have_symbolic || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
       tm.start(s);
       pfv::build_topology(*h);
@@ -352,7 +353,10 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
         pfv::launch_node_kernel(*h, nullptr, h->aux_stream);
         tn.mark(h->aux_stream);
         tm.start(s);
-        pfv::build_symbolic(*h);
+        // (the pattern of A is only needed by the assembly: PFV_SYMB_DEFER_CELLS=1 builds it beside the face kernel,
+        // below -- measured: interaction-region span 14.2 -> 13.2 ms, face span 7.2 -> 9.1 ms, step +0.5 ms: off)
+        cells_deferred = !h->subface_bc && pfv::env_int("PFV_SYMB_DEFER_CELLS", 0) != 0;
+        pfv::build_symbolic(*h, cells_deferred ? 1 : 3);
         h->stats.symbolic_ms = tm.stop(s);
         fork.join();                              // s waits for the node kernel
         h->stats.node_ms = tn.elapsed_after_sync();
@@ -385,21 +389,32 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
       // when the solve is going to work on the system in place (grid numbered along the Morton curve),
       // it is built now on the second stream, beside the face kernel, instead of inside pfv_solve.
       h->win_sys_prebuilt = h->win_rows_prebuilt = false;
-      const bool prebuild = h->aux_stream && h->have_cell_order && h->cell_order_identity &&
-                            pfv::env_int("PFV_OVERLAP_WINDOW", 1) != 0 && pfv::env_int("PFV_REORDER", 1) != 0 &&
-                            h->pat_A.nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000);
+      // (sizes of A's pattern: known now, or -- pattern deferred -- an upper estimate that only decides whether the
+      // second stream is used at all; the exact test follows once the pattern exists)
+      const int64_t nnzA_guess = cells_deferred ? h->pat_flux.nnz : h->pat_A.nnz;
+      bool prebuild = h->aux_stream && h->have_cell_order && h->cell_order_identity &&
+                      pfv::env_int("PFV_OVERLAP_WINDOW", 1) != 0 && pfv::env_int("PFV_REORDER", 1) != 0 &&
+                      nnzA_guess >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000);
       // (a sharded solve multiplies the rows of the owned cells: the window of those rows, for the
       // number of owned rows of the previous solve on this handle)
       h->win_rows_prebuilt = false;
-      const bool prebuild_rows = !prebuild && h->aux_stream && h->win_rows_n > 0 && h->win_rows_n <= h->pat_A.nrows &&
-                                 pfv::env_int("PFV_OVERLAP_WINDOW", 1) != 0 &&
-                                 h->pat_A.nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000);
-      if (prebuild || prebuild_rows) {
+      bool prebuild_rows = !prebuild && h->aux_stream && h->win_rows_n > 0 && h->win_rows_n <= h->nc &&
+                           pfv::env_int("PFV_OVERLAP_WINDOW", 1) != 0 &&
+                           nnzA_guess >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000);
+      if (prebuild || prebuild_rows || cells_deferred) {
         pfv::StreamFork fork(s, h->aux_stream);
         pfv::run_face_kernel(*h, with_vs);
         h->stream = h->aux_stream;
         try {
-          if (prebuild) {
+          if (cells_deferred) {
+            pfv::build_symbolic(*h, 2);
+            cells_deferred = false;
+            const bool big = h->pat_A.nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000);
+            prebuild = prebuild && big;
+            prebuild_rows = prebuild_rows && big;
+          }
+          if (!prebuild && !prebuild_rows) {
+          } else if (prebuild) {
             // the windows are a function of A's pattern alone: kept when the symbolic phase has just proved the
             // pattern equal to the one they were built for (sizes + checksum of the index arrays)
             const bool keep = h->win_sys.ok && h->pat_A_checksum != 0 && h->win_sys_checksum == h->pat_A_checksum &&
@@ -424,7 +439,7 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
         if (prebuild) {
           h->win_for = h->pat_A.indices.p;
           h->win_sys_prebuilt = true;
-        } else {
+        } else if (prebuild_rows) {
           h->win_rows_for = h->pat_A.indices.p;
           h->win_rows_prebuilt = true;
         }
@@ -432,6 +447,7 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
 #endif
       pfv::run_face_kernel(*h, with_vs);
     }
+    if (cells_deferred) pfv::build_symbolic(*h, 2);  // (no second stream was used)
     h->stats.face_ms = tm.stop(s);
     h->stats.discretize_ms = tall.stop(s);
     h->have_numeric = true;
@@ -1508,6 +1524,7 @@ static pfv::LinSys solver_system(pfv_ctx* h, bool& permuted) {
       h->win_sys_checksum = 0;
       pfv::win_build(*h, *sys.P, h->win_sys);
       h->win_for = sys.P->indices.p;
+      if (h->win_sys.ok && sys.P == &h->pat_A && h->have_symbolic) h->win_sys_checksum = h->pat_A_checksum;
     }
     sys.win = &h->win_sys;
   }
