@@ -395,7 +395,7 @@ class PinnedPool:
     whatever scipy matrix holds it) is garbage-collected the block is kept for the next request of the same size --
     the matrices of a time-stepping loop have the same sizes step after step, so after the first step no memory is
     pinned, unpinned or page-faulted any more.  Requests below ``min_bytes`` use plain numpy arrays; at most
-    ``PFV_PINNED_POOL_GB`` (default 48) are kept; ``PFV_PINNED_POOL=0`` switches the pool off."""
+    ``PFV_PINNED_POOL_GB`` (default: a quarter of the available host memory, at most 48) are kept, and the last ``Context`` of a library to close releases them; ``PFV_PINNED_POOL=0`` switches the pool off."""
 
     min_bytes = 1 << 20
 
@@ -405,7 +405,18 @@ class PinnedPool:
         self.lib = lib
         self.free: dict = {}
         self.cached = 0
-        self.cap = int(float(os.environ.get("PFV_PINNED_POOL_GB", "48")) * (1 << 30))
+        # cap of what is KEPT page-locked between uses: PFV_PINNED_POOL_GB, default a quarter of the memory that is
+        # available now (at most 48 GB) -- the eager matrices of a 2 M-cell grid are 23 GB; a small host keeps less
+        default_gb = 48.0
+        try:
+            with open("/proc/meminfo") as fh:
+                for line in fh:
+                    if line.startswith("MemAvailable:"):
+                        default_gb = min(48.0, 0.25 * int(line.split()[1]) / (1 << 20))
+                        break
+        except OSError:
+            pass
+        self.cap = int(float(os.environ.get("PFV_PINNED_POOL_GB", str(default_gb))) * (1 << 30))
         self.enabled = os.environ.get("PFV_PINNED_POOL", "1") not in ("0", "")
         self.allocated = 0  # statistics: blocks ever page-locked / requests served from the pool
         self.reused = 0
@@ -448,6 +459,7 @@ class PinnedPool:
 
 
 _POOLS: dict = {}
+_OPEN_CONTEXTS: dict = {}  # id(library) -> live Context handles
 
 
 def pinned_pool(lib) -> PinnedPool:
@@ -479,6 +491,7 @@ class Context:
             self._h = _h()
             raise PorefvError(st, "pfv_create failed: no usable MI355X / HIP device "
                                   "(the product path has no CPU fallback)")
+        _OPEN_CONTEXTS[id(self.lib)] = _OPEN_CONTEXTS.get(id(self.lib), 0) + 1
         self.nd = self.nc = self.nf = self.nn = 0
         self._discretized = False  # a complete MPFA discretization is resident on the device
         self._discretized_m = False  # ... MPSA
@@ -508,6 +521,11 @@ class Context:
                     m.close()
             self.lib.pfv_destroy(self._h)
             self._h = _h()
+            # the last handle of a library to go releases the page-locked blocks its result arrays were recycled through
+            n_open = _OPEN_CONTEXTS.get(id(self.lib), 1) - 1
+            _OPEN_CONTEXTS[id(self.lib)] = n_open
+            if n_open <= 0 and id(self.lib) in _POOLS:
+                _POOLS[id(self.lib)].trim()
 
     def __del__(self):
         try:
