@@ -253,6 +253,7 @@ struct pfv_ctx_impl {
   Buf<unsigned long long> csum_work;       // partial sums of launch_pattern_checksum
   unsigned long long pat_A_checksum = 0;   // checksum of pat_A's index arrays left by the symbolic phase (0: none)
   unsigned long long win_sys_checksum = 0; // ... of the pattern win_sys was built for (0: unknown)
+  unsigned long long win_rows_checksum = 0; // ... of the pattern whose leading win_rows_n rows win_rows covers
   unsigned long long symbolic_epoch = 0;  // bumped by every symbolic phase: saved AMG aggregates die with it
   std::unique_ptr<BlockPc> block_pc;  // pfv_set_block_preconditioner
   std::unique_ptr<Amg> amg_block;    // pfv_amg_setup: hierarchy of the leading block (sharded solves)
@@ -260,6 +261,9 @@ struct pfv_ctx_impl {
   Buf<double> val_block;
   // set only while pfv_solve_sharded runs: the caller's exchange hooks and work space
   const pfv_shard_hooks* shard = nullptr;
+  bool shard_overlap = false;        // sharded SpMV: halo exchange on aux_stream beside the interior row blocks
+  Buf<int32_t> shard_blocks;         // [interior row blocks | boundary row blocks] of win_rows
+  int64_t shard_n_interior = 0, shard_n_boundary = 0;
   Buf<double> red5;                  // block partials of the sharded BiCGStab's five merged sums
   double* shard_work = nullptr;      // [2 * shard_nloc + 8]: the two SpMV inputs (owned + halo entries), reduction scratch
   int64_t shard_nloc = 0;

@@ -7,6 +7,9 @@
 #include <cstring>
 
 #include "ctx.h"
+namespace pfv {
+static int rccl_exchange_halo(void* user, double* d_x, void* stream);  // rccl_hooks.inc
+}
 #include "topology.inc"
 #include "mpfa_numeric.inc"
 #include "linalg.inc"
@@ -427,8 +430,16 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
               if (h->win_sys.ok) h->win_sys_checksum = h->pat_A_checksum;
             }
           } else {
-            RowsView rows(h->pat_A, h->win_rows_n);
-            pfv::win_build(*h, rows.V, h->win_rows);
+            // (the window of the owned rows of a sharded solve: kept like win_sys when A's pattern is proved equal)
+            const bool keep = h->win_rows.ok && h->pat_A_checksum != 0 && h->win_rows_checksum == h->pat_A_checksum &&
+                              h->win_rows.nrows == h->win_rows_n && pfv::env_int("PFV_WIN_REUSE", 1) != 0;
+            h->stats.win_reused = keep ? 1 : 0;
+            if (!keep) {
+              h->win_rows_checksum = 0;
+              RowsView rows(h->pat_A, h->win_rows_n);
+              pfv::win_build(*h, rows.V, h->win_rows);
+              if (h->win_rows.ok) h->win_rows_checksum = h->pat_A_checksum;
+            }
           }
         } catch (...) {
           h->stream = s;
@@ -1209,6 +1220,7 @@ pfv_status pfv_spmv_device_rows(pfv_ctx* h, int which, int64_t nrows, const doub
         // the matrix is assembled again
         if (h->win_rows_for != P.indices.p || h->win_rows_n != nrows) {
           V.nnz = P.nnz;  // (lidx is indexed by entry position)
+          h->win_rows_checksum = 0;
           pfv::win_build(*h, V, h->win_rows);
           h->win_rows_for = P.indices.p;
           h->win_rows_n = nrows;
@@ -1629,8 +1641,10 @@ pfv_status pfv_solve_sharded(pfv_ctx* h, int method, double rtol, int maxit, int
     sys.win = nullptr;
     if (P.nnz >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000)) {
       if (h->win_rows_for != P.indices.p || h->win_rows_n != n_own) {
+        h->win_rows_checksum = 0;
         pfv::win_build(*h, rows.V, h->win_rows);
         h->win_rows_for = P.indices.p;
+        if (h->win_rows.ok && &P == &h->pat_A && h->have_symbolic) h->win_rows_checksum = h->pat_A_checksum;
         h->win_rows_n = n_own;
       }
       if (h->win_rows.ok) sys.win = &h->win_rows;
@@ -1645,6 +1659,40 @@ pfv_status pfv_solve_sharded(pfv_ctx* h, int method, double rtol, int maxit, int
     }
     pfv::be_memset(d_x_owned, 0, sizeof(double) * (size_t)n_own, s);
     pfv::be_memset(d_work, 0, sizeof(double) * (size_t)(2 * n_loc + 8), s);
+    h->shard_overlap = false;
+#ifndef PFV_EMULATE
+    {
+      // PFV_SHARD_OVERLAP=1: halo exchange of the Krylov products on the second stream beside the row blocks that need
+      // no halo entry (linalg.inc: shard_spmv) -- with the native RCCL hooks only (a caller's hooks are not known to
+      // honour a foreign stream).  OFF by default: no two-GPU box has run it yet.  =2 (tests): every second block
+      // counts as a boundary block.
+      const int ov = pfv::env_int("PFV_SHARD_OVERLAP", 0);
+      if (ov != 0 && sys.win && sys.win->ok && h->aux_stream && hooks->exchange_halo == &pfv::rccl_exchange_halo) {
+        const pfv::WinCsr& W = *sys.win;
+        const int64_t nblk = W.nblk;
+        int32_t* lst = h->shard_blocks.ensure(2 * nblk + 2);
+        int32_t* cnt = h->status.ensure(16);
+        pfv::be_memset(cnt + 12, 0, 2 * sizeof(int32_t), s);
+        const int64_t* wptr = W.wptr64;
+        const int32_t* wlen = W.wlen;
+        const int32_t* wcol = W.wcol.p;
+        int32_t* tmp_b = lst + nblk;  // boundary blocks collected behind, moved up below
+        pfv::parallel_for(s, nblk, PFV_LAMBDA(int64_t b) {
+          const int64_t w0 = wptr[b];
+          const int wn = wlen ? wlen[b] : (int)(wptr[b + 1] - w0);
+          const bool bnd = ov == 2 ? (b & 1) != 0 : (wn > 0 && wcol[w0 + wn - 1] >= n_own);  // (window columns ascend)
+          if (bnd) tmp_b[atomicAdd(cnt + 13, 1)] = (int32_t)b;
+          else lst[atomicAdd(cnt + 12, 1)] = (int32_t)b;
+        });
+        int32_t hc[2];
+        be_d2h(hc, cnt + 12, sizeof(hc), s);
+        h->shard_n_interior = hc[0];
+        h->shard_n_boundary = hc[1];
+        pfv::be_d2d(lst + hc[0], tmp_b, sizeof(int32_t) * (size_t)hc[1], s);
+        h->shard_overlap = true;
+      }
+    }
+#endif
     h->shard = hooks;
     h->shard_work = d_work;
     h->shard_nloc = n_loc;

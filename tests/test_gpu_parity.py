@@ -264,6 +264,54 @@ def test_sharded_driver_single_rank_with_block_amg(lib):
     torch.cuda.synchronize()
 
 
+def test_sharded_products_split_into_interior_and_boundary_row_blocks(lib, monkeypatch):
+    """PFV_SHARD_OVERLAP: the Krylov products of a sharded solve in two launches -- row blocks without halo columns
+    beside the halo exchange (second stream), the others after it.  One rank over the native RCCL hooks (the box has
+    one GPU): in test mode (=2) every second row block counts as a boundary block; the split must not change a bit of
+    the solution (every block keeps its slot of the reduction partials)."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from porepy_amd import distributed as D
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([16, 16, 16], [1, 1, 1])), 0.02)
+        rng = np.random.default_rng(1)
+        k = np.exp(0.5 * rng.standard_normal(g.num_cells))
+        K = pa.SecondOrderTensor(kxx=k, kyy=6 * k, kzz=0.3 * k, kxy=0.3 * k)
+        bf = g.get_all_boundary_faces()
+        dirf = bf[(g.face_centers[0, bf] < 1e-9) | (g.face_centers[0, bf] > 1 - 1e-9)]
+        bc = pa.BoundaryCondition(g, dirf, ["dir"] * dirf.size)
+        bv = np.zeros(g.num_faces)
+        bv[dirf] = g.face_centers[0, dirf]
+        raw = pa.grid_to_raw(g)
+        lp = D.extract_subdomain(raw, np.zeros(g.num_cells, dtype=np.int64), 0)
+        sh = D.ShardedMpfa(lp, device="cuda:0", local_device_index=0, library=lib, dist=dist)
+        sh.discretize(K.values[:, :, lp.cell_gid], sh.local_bc_flags(pa.bc_flags(bc)[lp.face_gid]), None, 1.0 / 3.0)
+        sh.assemble(bv[lp.face_gid], g.cell_volumes[lp.cell_gid])
+        sols = {}
+        for mode in ("0", "2", "1"):
+            monkeypatch.setenv("PFV_SHARD_OVERLAP", mode)
+            x, info = sh.solve("bicgstab", rtol=1e-12, precond="amg")
+            assert info["transport"].startswith("rccl") and info["converged"]
+            sols[mode] = (x.cpu().numpy().copy(), info["iterations"])
+        assert sols["2"][1] == sols["0"][1] and np.array_equal(sols["2"][0], sols["0"][0])
+        assert sols["1"][1] == sols["0"][1] and np.array_equal(sols["1"][0], sols["0"][0])  # (one rank: no boundary block)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("name", ["subface_cart2d_4x3", "subface_tet3d_2x2x2"])
 @pytest.mark.parametrize("scramble", [False, True])
 def test_boundary_conditions_per_subface(lib, name, scramble):
