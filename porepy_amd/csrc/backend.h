@@ -461,6 +461,23 @@ __global__ void __launch_bounds__(64) k_wave_for(int64_t n, size_t lds_per_item,
     __syncthreads();
   }
 }
+// The same with a register budget: at least W wavefronts per SIMD must fit (amdgpu_waves_per_eu), i.e. the compiler
+// keeps the kernel within 512 / W VGPRs -- for kernels whose occupancy would otherwise fall below what their LDS
+// footprint allows (the interaction-region kernel: 177 VGPRs = 2 per SIMD, its 17 KB of LDS allow 9 per CU).
+template <int G, int W, class F>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W))) k_wave_for_occ(int64_t n, size_t lds_per_item, F f) {
+  extern __shared__ __attribute__((aligned(16))) char pfv_lds[];
+  constexpr int per_block = 64 / G;
+  const int grp = (int)threadIdx.x / G;
+  for (int64_t b0 = (int64_t)blockIdx.x * per_block; b0 < n; b0 += (int64_t)gridDim.x * per_block) {
+    const int64_t b = b0 + grp;
+    if (b < n) {
+      WaveCtx w{b, pfv_lds + (size_t)grp * lds_per_item, (int)threadIdx.x % G, G, nullptr};
+      f(w);
+    }
+    __syncthreads();
+  }
+}
 // Same, with the items split into 8 contiguous ranges, one per XCD (workgroup b is observed to run on
 // XCD b % 8; a speed assumption only): work items that are neighbours in the item order share one L2.
 // gridDim.x is a multiple of 8.
@@ -526,6 +543,27 @@ inline void wave_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
   PFV_HIP_CHECK(hipGetLastError());
 #endif
 }
+
+#ifndef PFV_EMULATE
+// wave_for with at least W wavefronts per SIMD guaranteed by the register allocation (k_wave_for_occ)
+template <int G, int W, class F>
+inline void wave_for_occ(stream_t s, int64_t n, size_t lds_bytes, F f) {
+  if (n <= 0) return;
+  lds_bytes = (lds_bytes + 15) & ~size_t(15);
+  constexpr int per_block = 64 / G;
+  const size_t block_lds = lds_bytes * per_block;
+  if (block_lds > 160 * 1024) throw Error(5, "work item needs more than 160 KiB of LDS");
+  int64_t blocks = (n + per_block - 1) / per_block;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (block_lds > 48 * 1024) {
+    PFV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_for_occ<G, W, F>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wave_for_occ<G, W, F>), dim3((unsigned)blocks), dim3(64), block_lds, s, n,
+                     lds_bytes, f);
+  PFV_HIP_CHECK(hipGetLastError());
+}
+#endif
 
 // wave_for with the lane-group width picked at run time (16 / 32 / 64): the one-item-per-wavefront
 // kernels are bound by the latency of their dependent index loads, so narrower groups (more items
@@ -751,6 +789,20 @@ PFV_HD inline void atomic_min_i32(int* addr, int v) {
   atomicMin(addr, v);
 #else
   (void)addr; (void)v;
+#endif
+#endif
+}
+PFV_HD inline int atomic_fetch_add_i32(int* addr, int v) {
+#ifdef PFV_EMULATE
+  const int old = *addr;
+  *addr += v;
+  return old;
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicAdd(addr, v);
+#else
+  (void)addr; (void)v;
+  return 0;
 #endif
 #endif
 }

@@ -264,6 +264,11 @@ struct pfv_ctx_impl {
   bool shard_overlap = false;        // sharded SpMV: halo exchange on aux_stream beside the interior row blocks
   Buf<int32_t> shard_blocks;         // [interior row blocks | boundary row blocks] of win_rows
   int64_t shard_n_interior = 0, shard_n_boundary = 0;
+  Buf<int32_t> node_redo;            // nodes the lean MPFA launches hand to the full body (mpfa_numeric.inc)
+  std::function<void(stream_t, int64_t)> node_redo_launch;  // ... and the launch that takes them (set by launch_node_kernel)
+  int64_t stats_node_redo = 0;
+  Buf<int32_t> mpsa_redo;            // nodes the lean MPSA launches hand to the full body (mpsa.inc)
+  int64_t stats_mpsa_redo = 0;
   Buf<double> red5;                  // block partials of the sharded BiCGStab's five merged sums
   double* shard_work = nullptr;      // [2 * shard_nloc + 8]: the two SpMV inputs (owned + halo entries), reduction scratch
   int64_t shard_nloc = 0;
