@@ -724,6 +724,51 @@ inline void exclusive_scan(stream_t s, Scratch& sc, const TI* in, TO* out, size_
 #endif
 }
 
+// A device double read back WITHOUT draining the stream: issue() enqueues the copy into page-locked memory and records
+// an event behind it; take() waits for that event only -- whatever was enqueued after the copy keeps the GPU busy
+// meanwhile.  (A plain read_scalar makes the host wait for everything and the GPU then idles until the next launch
+// arrives: 120 us per BiCGStab iteration on the 2 M-cell system.)
+struct LaggedScalar {
+  bool pending = false;
+#ifdef PFV_EMULATE
+  const double* src = nullptr;
+  void issue(const double* dptr, stream_t) { src = dptr; pending = true; }
+  double take() { pending = false; return *src; }
+#else
+  double* host = nullptr;
+  hipEvent_t ev = nullptr;
+  void issue(const double* dptr, stream_t s) {
+    if (!host) {
+      PFV_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocDefault));
+      PFV_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    PFV_HIP_CHECK(hipMemcpyAsync(host, dptr, sizeof(double), hipMemcpyDeviceToHost, s));
+    PFV_HIP_CHECK(hipEventRecord(ev, s));
+    pending = true;
+  }
+  double take() {
+    if (spin_wait_enabled()) {
+      for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) PFV_HIP_CHECK(e);
+      }
+    } else {
+      PFV_HIP_CHECK(hipEventSynchronize(ev));
+    }
+    pending = false;
+    return *host;
+  }
+  ~LaggedScalar() {
+    if (host) (void)hipHostFree(host);
+    if (ev) (void)hipEventDestroy(ev);
+  }
+#endif
+  LaggedScalar() = default;
+  LaggedScalar(const LaggedScalar&) = delete;
+  LaggedScalar& operator=(const LaggedScalar&) = delete;
+};
+
 template <class T>
 inline T read_scalar(stream_t s, const T* dptr) {
   T v;

@@ -264,6 +264,7 @@ struct pfv_ctx_impl {
   bool shard_overlap = false;        // sharded SpMV: halo exchange on aux_stream beside the interior row blocks
   Buf<int32_t> shard_blocks;         // [interior row blocks | boundary row blocks] of win_rows
   int64_t shard_n_interior = 0, shard_n_boundary = 0;
+  LaggedScalar lag_rr;               // residual norm of the Krylov loop, read half an iteration late (linalg.inc)
   Buf<int32_t> node_redo;            // nodes the lean MPFA launches hand to the full body (mpfa_numeric.inc)
   std::function<void(stream_t, int64_t)> node_redo_launch;  // ... and the launch that takes them (set by launch_node_kernel)
   int64_t stats_node_redo = 0;
