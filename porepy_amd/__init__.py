@@ -16,6 +16,7 @@ from .partial import active_indices
 from .solvers import HipLinearSolver, solve_block_system, solve_csr
 from .device_csr import DeviceCsr, block_diag, bmat, merged_matrix, vstack
 from . import ad
+from . import md_sharding
 from .tpfa import DifferentiableTpfa, Tpfa, as_porepy_ad_tpfa_flux
 from .params import (DISCRETIZATION_MATRICES, PARAMETERS, BoundaryCondition, BoundaryConditionVectorial,
                      FourthOrderTensor, SecondOrderTensor, bc_flags, bc_to_raw, initialize_data)
@@ -25,5 +26,5 @@ __all__ = [
     "StructuredTetrahedralGrid", "TetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "grid_from_raw", "Mpfa",
     "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition", "Mpsa",
     "FourthOrderTensor", "BoundaryConditionVectorial",
-    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa", "DifferentiableTpfa", "as_porepy_ad_tpfa_flux", "Biot", "as_porepy_mpsa", "as_porepy_biot", "DeviceCsr", "block_diag", "bmat", "merged_matrix", "vstack", "ad", "solve_block_system",
+    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa", "DifferentiableTpfa", "as_porepy_ad_tpfa_flux", "Biot", "as_porepy_mpsa", "as_porepy_biot", "DeviceCsr", "block_diag", "bmat", "merged_matrix", "vstack", "ad", "solve_block_system", "md_sharding",
 ]

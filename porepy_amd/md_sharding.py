@@ -1,0 +1,233 @@
+"""Mixed-dimensional grids shard BY SUBDOMAIN: the reference's discretization loop, one share per GPU.
+
+The reference discretizes a mixed-dimensional model in one serial loop over (discretization object, grid)
+pairs -- ``pp.ad.discretize_from_list`` (/root/reference/src/porepy/numerics/ad/ad_utils.py:281-308), called by
+``EquationSystem.discretize`` (numerics/ad/equation_system.py:1529-1559) and by the nonlinear re-discretization of
+the models (models/solution_strategy.py:995, 1014).  Every pair is independent of the others: the call reads
+``data[PARAMETERS]`` of its grid(s) and stores matrices under ``data[DISCRETIZATION_MATRICES]``.  That is the natural
+partition of BASELINE configs[4] (a 52-fracture network: one 3-D matrix grid, 52 fracture planes, ~100 intersection
+lines, the mortar grids between them): no halo, no collective inside the assembly.
+
+``discretize_from_list_sharded`` is the same loop with the pairs dealt out to the ranks (longest job first onto
+the least loaded rank, the cost of a pair taken from its cell count and dimension), each rank running its share on
+its own GPU through whatever ``pp.Mpfa`` / ``pp.Mpsa`` are bound to, and ONE exchange at the end in which every
+rank hands the matrices its jobs stored to all others (``torch.distributed.all_gather_object`` on the group given
+-- RCCL on the GPU box, gloo in the CPU tests).  After the call every rank holds the data dictionaries the serial
+loop would have left: the AD assembly of the Jacobian (which the reference does in one process) can run anywhere.
+``sharded_discretization(pp, ...)`` rebinds ``pp.ad.discretize_from_list`` for the duration of a ``with`` block, so
+an unmodified model shards its discretization -- the same kind of rebind as ``pp.Mpfa = HipMpfa``.
+
+A single large grid is not split here (that is ``distributed.extract_subdomain`` / ``ShardedCsr``: cells + one node
+ring): with one 3-D grid carrying most of the cells, the speed-up of this loop is bounded by
+``sum(cost) / max(cost)`` -- ``plan()`` reports it.
+"""
+from __future__ import annotations
+
+import contextlib
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sps
+
+
+@dataclass
+class Job:
+    """One call of the reference's loop: ``discr.discretize(grid, data)`` or the interface form."""
+
+    discr: object
+    grid: object
+    is_interface: bool
+    cost: float = 0.0
+    owner: int = 0
+
+
+@dataclass
+class Plan:
+    jobs: list
+    world: int
+    load: np.ndarray = field(default_factory=lambda: np.zeros(0))
+
+    @property
+    def bound(self) -> float:
+        """Largest possible speed-up of the loop: total cost / largest single job."""
+        c = np.array([j.cost for j in self.jobs])
+        return float(c.sum() / c.max()) if c.size and c.max() > 0 else 1.0
+
+    @property
+    def speedup(self) -> float:
+        """Speed-up of this assignment by the cost model: total cost / load of the busiest rank."""
+        return float(self.load.sum() / self.load.max()) if self.load.size and self.load.max() > 0 else 1.0
+
+    def summary(self) -> dict:
+        return {"jobs": len(self.jobs), "world": self.world, "load": [float(x) for x in self.load],
+                "speedup_by_cost_model": self.speedup, "bound_total_over_largest_job": self.bound,
+                "jobs_per_rank": [int(sum(1 for j in self.jobs if j.owner == r)) for r in range(self.world)]}
+
+
+# cost of one (discretization, grid) pair relative to a 3-D cell of a local-system discretization
+_LOCAL_SYSTEM = ("Mpfa", "Mpsa", "Biot")
+
+
+def default_cost(discr, grid, is_interface: bool) -> float:
+    """Relative cost: the interaction-region discretizations dominate (a 3-D tetrahedral cell costs ~7x a 2-D one:
+    36 sub-faces per node against 12, cubic in the elimination); two-point / upwind / coupling discretizations
+    are a pass over the cells."""
+    n = float(getattr(grid, "num_cells", 1))
+    if is_interface:
+        return 0.02 * n + 1.0
+    name = type(discr).__name__
+    bases = {b.__name__ for b in type(discr).__mro__}
+    dim = int(getattr(grid, "dim", 0))
+    if dim >= 2 and (bases & set(_LOCAL_SYSTEM) or any(t in name for t in _LOCAL_SYSTEM)):
+        return n * (1.0 if dim == 3 else 0.15) * (3.0 if ("Mpsa" in bases or "Biot" in bases) else 1.0) + 1.0
+    return 0.02 * n + 1.0
+
+
+def plan(discretizations: dict, world: int, cost=None, is_interface=None) -> Plan:
+    """The jobs of ``discretize_from_list`` in the reference's own order, with an owner each.
+
+    Longest-processing-time-first: jobs by decreasing cost (ties: loop order) onto the least loaded rank (ties:
+    lowest rank) -- deterministic, every rank computes the same plan without talking."""
+    cost = cost or default_cost
+    if is_interface is None:
+        def is_interface(g):
+            return hasattr(g, "mortar_to_primary_int") or type(g).__name__ == "MortarGrid"
+    jobs = []
+    for discr in discretizations:
+        for grid in discretizations[discr]:
+            intf = bool(is_interface(grid))
+            jobs.append(Job(discr, grid, intf, float(cost(discr, grid, intf))))
+    load = np.zeros(max(1, int(world)))
+    order = sorted(range(len(jobs)), key=lambda i: (-jobs[i].cost, i))
+    for i in order:
+        r = int(np.argmin(load))
+        jobs[i].owner = r
+        load[r] += jobs[i].cost
+    return Plan(jobs, max(1, int(world)), load)
+
+
+_ABSENT = object()
+
+
+def _host_value(v):
+    """What travels: scipy matrices / numpy arrays / plain Python values.  Device-resident and lazily fetched
+    matrices of this package are fetched (``DeviceCsr.to_scipy`` / ``LazyCsr.tocsr``)."""
+    if sps.issparse(v) or isinstance(v, (np.ndarray, float, int, str, bool, type(None))):
+        return v
+    if hasattr(v, "to_scipy"):
+        return v.to_scipy()
+    if hasattr(v, "tocsr"):
+        return v.tocsr()
+    return v
+
+
+def _matrix_slots(pp, mdg, job: Job):
+    """The data dictionaries a job may write to (ad_utils.py:294-305)."""
+    if job.is_interface:
+        g_primary, g_secondary = mdg.interface_to_subdomain_pair(job.grid)
+        return [mdg.subdomain_data(g_primary), mdg.subdomain_data(g_secondary), mdg.interface_data(job.grid)]
+    return [mdg.subdomain_data(job.grid)]
+
+
+def _snapshot(pp, slots):
+    snap = {}
+    for s, d in enumerate(slots):
+        for kw, md in d.get(pp.DISCRETIZATION_MATRICES, {}).items():
+            for name, v in md.items():
+                snap[(s, kw, name)] = v  # (the object itself: an id could be recycled once the job overwrites it)
+    return snap
+
+
+def _run(pp, mdg, job: Job, slots):
+    if job.is_interface:
+        g_primary, g_secondary = mdg.interface_to_subdomain_pair(job.grid)
+        job.discr.discretize(g_primary, g_secondary, job.grid, slots[0], slots[1], slots[2])
+    else:
+        try:
+            job.discr.discretize(job.grid, slots[0])
+        except NotImplementedError:  # (as the reference: GradP and other Biot helpers, ad_utils.py:306-308)
+            pass
+
+
+def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None, rank: int | None = None,
+                                 world: int | None = None, cost=None, exchange=None, stats: dict | None = None):
+    """``pp.ad.discretize_from_list`` (ad_utils.py:281-308) with the (discretization, grid) pairs dealt out to ranks.
+
+    ``exchange(payload) -> list of payloads by rank`` defaults to ``torch.distributed.all_gather_object`` on
+    ``group``; with ``world == 1`` the call IS the reference's loop.  ``stats`` (a dict) receives the plan summary,
+    the jobs run here and the bytes of matrices sent."""
+    if pp is None:
+        import porepy as pp  # noqa: PLC0415  (the reference package this loop belongs to)
+    if exchange is None and (world is None or rank is None):
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(group) if world is None else world
+            rank = dist.get_rank(group) if rank is None else rank
+        else:
+            world, rank = 1, 0
+    pl = plan(discretizations, world, cost, is_interface=lambda g: isinstance(g, pp.MortarGrid))
+    mine: dict = {}
+    for i, job in enumerate(pl.jobs):
+        if job.owner != rank:
+            continue
+        slots = _matrix_slots(pp, mdg, job)
+        before = _snapshot(pp, slots)
+        _run(pp, mdg, job, slots)
+        out = []
+        for s, d in enumerate(slots):
+            for kw, md in d.get(pp.DISCRETIZATION_MATRICES, {}).items():
+                for name, v in md.items():
+                    if before.get((s, kw, name), _ABSENT) is not v:
+                        out.append((s, kw, name, _host_value(v)))
+        mine[i] = out
+    sent = 0
+    if world > 1:
+        if exchange is None:
+            import torch.distributed as dist
+
+            def exchange(payload):
+                got = [None] * world
+                dist.all_gather_object(got, payload, group=group)
+                return got
+        for r, theirs in enumerate(exchange(mine)):
+            if r == rank:
+                continue
+            for i in sorted(theirs):
+                slots = _matrix_slots(pp, mdg, pl.jobs[i])
+                for (s, kw, name, v) in theirs[i]:
+                    slots[s].setdefault(pp.DISCRETIZATION_MATRICES, {}).setdefault(kw, {})[name] = v
+        for out in mine.values():
+            for (_, _, _, v) in out:
+                if sps.issparse(v):
+                    m = v.tocsr() if not sps.isspmatrix_csr(v) and not sps.isspmatrix_csc(v) else v
+                    sent += m.data.nbytes + m.indices.nbytes + m.indptr.nbytes
+                elif isinstance(v, np.ndarray):
+                    sent += v.nbytes
+    if stats is not None:
+        stats.setdefault("calls", 0)
+        stats["calls"] += 1
+        stats["plan"] = pl.summary()
+        stats.setdefault("plans", []).append(stats["plan"])
+        stats["jobs_run_here"] = stats.get("jobs_run_here", 0) + len(mine)
+        stats["matrix_bytes_sent"] = stats.get("matrix_bytes_sent", 0) + int(sent)
+        stats["rank"] = rank
+    return pl
+
+
+@contextlib.contextmanager
+def sharded_discretization(pp, group=None, rank: int | None = None, world: int | None = None, cost=None,
+                           exchange=None, stats: dict | None = None):
+    """Rebind ``pp.ad.discretize_from_list`` (the loop every model discretizes through: equation_system.py:1559,
+    solution_strategy.py:995 / 1014, operators.py:487) to the sharded loop inside the ``with`` block."""
+    orig = pp.ad.discretize_from_list
+
+    def sharded(discretizations, mdg):
+        return discretize_from_list_sharded(discretizations, mdg, pp=pp, group=group, rank=rank, world=world,
+                                            cost=cost, exchange=exchange, stats=stats)
+
+    pp.ad.discretize_from_list = sharded
+    try:
+        yield sharded
+    finally:
+        pp.ad.discretize_from_list = orig

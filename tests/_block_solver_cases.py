@@ -61,3 +61,34 @@ def flow_blocks_with_amg(lib, n=14):
     assert info["converged"] and not info["rows_matched"] and info["true_rel_residual"] < 1e-11
     assert N > 1024 and info["iterations"] < 40
     return info["iterations"]
+
+
+def thermo_hydro_jacobian_52_fractures(lib):
+    """The third Newton system of the thermo-hydro model on the 52-fracture network (tests/_dropin_c5_script.py --save:
+    21 360 unknowns; 385 interfaces with three flux variables each).  Sweeps over (variable, grid) or variable-wide
+    blocks do not converge on it (returned as "without_condensation_converged"); with the interface unknowns condensed
+    on the device (solve_block_system: eliminate) GMRES and BiCGStab reach the direct solution."""
+    z = np.load(os.path.join(GOLDEN, "md_thermal_jacobian_box_52fractures.npz"))
+    A = sps.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    b, block_of, row_perm, interface = z["b"], z["block_of"], z["row_perm"], z["interface"]
+    assert A.shape[0] == 21360 and int(interface.sum()) == 3 * 3392 and np.unique(block_of).size == 5
+    x_ref = spla.spsolve(A.tocsc(), b)
+    out = {}
+    for method in ("gmres", "bicgstab"):
+        x, info = solvers.solve_block_system(A, b, block_of, method=method, rtol=1e-13, restart=80, library=lib,
+                                             row_perm=row_perm, eliminate=interface)
+        assert info["converged"] and info["condensed_unknowns"] == int(interface.sum())
+        assert info["true_rel_residual"] < 1e-12
+        assert np.linalg.norm(x - x_ref) <= 1e-10 * np.linalg.norm(x_ref)
+        out[method] = info["iterations"]
+    _, info = solvers.solve_block_system(A, b, block_of, rtol=1e-13, restart=80, maxit=160, library=lib, row_perm=row_perm)
+    out["without_condensation_converged"] = bool(info["converged"])
+    # a block is condensed as a whole or not at all
+    half = interface.copy()
+    half[np.where(interface)[0][::2]] = False
+    try:
+        solvers.solve_block_system(A, b, block_of, library=lib, row_perm=row_perm, eliminate=half)
+        raise AssertionError("a partly condensed block must be refused")
+    except ValueError:
+        pass
+    return out

@@ -22,3 +22,10 @@ def test_thermo_hydro_mixed_dimensional_jacobian_with_the_block_preconditioner(w
 @pytest.mark.parametrize("which", LIBS)
 def test_large_blocks_take_the_amg_cycle(which):
     assert B.flow_blocks_with_amg(_lib(which)) < 40
+
+
+@pytest.mark.parametrize("which", LIBS)
+def test_52_fracture_thermo_hydro_jacobian_with_condensed_interface_fluxes(which):
+    out = B.thermo_hydro_jacobian_52_fractures(_lib(which))
+    assert out["gmres"] <= 80 and out["bicgstab"] <= 60
+    assert not out["without_condensation_converged"]

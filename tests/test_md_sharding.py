@@ -1,0 +1,160 @@
+"""Subdomain sharding of the reference's discretization loop (porepy_amd/md_sharding.py; the loop:
+/root/reference/src/porepy/numerics/ad/ad_utils.py:281-308).  Stand-in grids and discretizations here (no reference
+needed); the real model under gloo is tests/test_reference_dropin.py::test_c5_*."""
+import threading
+import types
+
+import numpy as np
+import scipy.sparse as sps
+
+from porepy_amd import md_sharding as S
+
+
+class Grid:
+    def __init__(self, dim, n, name):
+        self.dim, self.num_cells, self.name = dim, n, name
+
+
+class MortarGrid(Grid):
+    pass
+
+
+class Mpfa:
+    def __init__(self, keyword):
+        self.keyword = keyword
+        self.ran = []
+
+    def discretize(self, sd, data):
+        self.ran.append(sd.name)
+        md = data.setdefault("discretization_matrices", {}).setdefault(self.keyword, {})
+        md["flux"] = sps.identity(sd.num_cells, format="csr") * (1 + len(self.keyword))
+        md["bound_flux"] = np.full(3, float(sd.num_cells))
+
+
+class GradP:
+    keyword = "mechanics"
+
+    def discretize(self, sd, data):
+        raise NotImplementedError
+
+
+class Coupling:
+    keyword = "flow"
+
+    def __init__(self):
+        self.ran = []
+
+    def discretize(self, g_h, g_l, intf, d_h, d_l, d_i):
+        self.ran.append(intf.name)
+        d_i.setdefault("discretization_matrices", {}).setdefault("flow", {})["mortar"] = sps.identity(intf.num_cells, format="csr")
+        d_h.setdefault("discretization_matrices", {}).setdefault("flow", {})["trace_of_" + intf.name] = np.arange(2.0)
+
+
+class Mdg:
+    def __init__(self):
+        self.g3 = Grid(3, 4000, "matrix")
+        self.fr = [Grid(2, 30 + 5 * i, f"fracture{i}") for i in range(12)]
+        self.intf = [MortarGrid(2, 30 + 5 * i, f"interface{i}") for i in range(12)]
+        self._data = {id(g): {} for g in [self.g3, *self.fr, *self.intf]}
+
+    def subdomain_data(self, g):
+        return self._data[id(g)]
+
+    interface_data = subdomain_data
+
+    def interface_to_subdomain_pair(self, intf):
+        return self.g3, self.fr[self.intf.index(intf)]
+
+
+def fake_pp():
+    return types.SimpleNamespace(DISCRETIZATION_MATRICES="discretization_matrices", MortarGrid=MortarGrid)
+
+
+def make():
+    mdg = Mdg()
+    discr = {Mpfa("flow"): [mdg.g3, *mdg.fr], Mpfa("fourier"): [mdg.g3, *mdg.fr], GradP(): [mdg.g3], Coupling(): list(mdg.intf)}
+    return mdg, discr
+
+
+def flat(mdg):
+    out = {}
+    for g in [mdg.g3, *mdg.fr, *mdg.intf]:
+        for kw, md in mdg.subdomain_data(g).get("discretization_matrices", {}).items():
+            for name, v in md.items():
+                out[(g.name, kw, name)] = v.toarray() if sps.issparse(v) else np.asarray(v)
+    return out
+
+
+def test_plan_is_deterministic_and_balanced():
+    mdg, discr = make()
+    p1 = S.plan(discr, 4)
+    p2 = S.plan(discr, 4)
+    assert [j.owner for j in p1.jobs] == [j.owner for j in p2.jobs]
+    assert len(p1.jobs) == 13 + 13 + 1 + 12
+    # the two 3-D interaction-region jobs dominate: they land on different ranks, the bound is total / largest
+    big = [j for j in p1.jobs if j.grid is mdg.g3 and isinstance(j.discr, Mpfa)]
+    assert len({j.owner for j in big}) == 2
+    assert abs(p1.bound - sum(j.cost for j in p1.jobs) / max(j.cost for j in p1.jobs)) < 1e-12
+    assert 1.0 < p1.speedup <= p1.bound + 1e-12
+    s = p1.summary()
+    assert sum(s["jobs_per_rank"]) == len(p1.jobs) and len(s["load"]) == 4
+    # one rank: everything stays
+    assert {j.owner for j in S.plan(discr, 1).jobs} == {0}
+
+
+def test_sharded_loop_leaves_what_the_serial_loop_leaves():
+    world = 3
+    pp = fake_pp()
+    mdg0, discr0 = make()
+    S.discretize_from_list_sharded(discr0, mdg0, pp=pp, rank=0, world=1)
+    serial = flat(mdg0)
+    assert all(len(d.ran) == len(g) for d, g in discr0.items() if hasattr(d, "ran"))
+
+    barrier = threading.Barrier(world)
+    box = [None] * world
+    results, stats, ran = [None] * world, [dict() for _ in range(world)], [None] * world
+    errors = []
+
+    def exchange_for(rank):
+        def exchange(payload):
+            box[rank] = payload
+            barrier.wait(timeout=60)
+            got = list(box)
+            barrier.wait(timeout=60)
+            return got
+        return exchange
+
+    def worker(rank):
+        try:
+            mdg, discr = make()
+            S.discretize_from_list_sharded(discr, mdg, pp=pp, rank=rank, world=world, exchange=exchange_for(rank), stats=stats[rank])
+            results[rank] = flat(mdg)
+            ran[rank] = sum(len(d.ran) for d in discr if hasattr(d, "ran"))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert not errors, errors
+    for r in range(world):
+        assert results[r].keys() == serial.keys()
+        assert all(np.array_equal(results[r][k], serial[k]) for k in serial)
+        assert stats[r]["plan"]["world"] == world and stats[r]["matrix_bytes_sent"] > 0
+    # every job ran exactly once over the ranks (the GradP job raises NotImplementedError on its owner, as in the reference)
+    assert sum(ran) == 13 + 13 + 12
+    assert sum(s["jobs_run_here"] for s in stats) == 39
+
+
+def test_rebind_context_restores_the_reference_loop():
+    calls = []
+    pp = fake_pp()
+    pp.ad = types.SimpleNamespace(discretize_from_list=lambda d, m: calls.append("reference"))
+    orig = pp.ad.discretize_from_list
+    mdg, discr = make()
+    with S.sharded_discretization(pp, rank=0, world=1):
+        assert pp.ad.discretize_from_list is not orig
+        pp.ad.discretize_from_list(discr, mdg)
+    assert pp.ad.discretize_from_list is orig and not calls
+    assert len(flat(mdg)) == len(flat(mdg)) > 0

@@ -116,6 +116,58 @@ def test_thermo_hydro_mixed_dimensional_model_with_rebound_mpfa(variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
+def test_c5_thermo_hydro_model_on_a_52_fracture_network(variant):
+    """BASELINE configs[4] at its stated network size: 52 fractures in a 3-D box (114 intersection lines, 23 points,
+    385 interfaces; structured stand-in for the gmsh geometry), the reference's MassAndEnergyBalance with ``pp.Mpfa``
+    rebound on all 190 subdomains and every Newton system (21 360 unknowns) solved on the device: GMRES on the system
+    with the interface fluxes condensed, variable-wide AMG blocks (porepy_amd.solvers: eliminate)."""
+    out = run_script("_dropin_c5_script.py", variant, 1500)
+    assert (out["fractures"], out["lines"], out["points"], out["interfaces"]) == (52, 114, 23, 385)
+    assert out["dofs"] == 21360
+    c = out["device_calls"]
+    assert c["flow:3"] >= 1 and c["flow:2"] >= 52 and c["fourier_discretization:2"] >= 52
+    assert out["T_range"][1] - out["T_range"][0] > 1.0
+    assert out["hip_linear_solves"] >= 3 and out["hip_solver_blocks"] == 5
+    assert out["hip_solver_max_iterations"] <= 120 and out["hip_solver_worst_true_residual"] < 1e-11
+    assert max(out["x_rel_err"], out["T_rel_err"], out["p_rel_err"], out["A_rel_err"]) < 1e-10
+
+
+def test_c5_discretization_sharded_by_subdomain_under_gloo():
+    """The reference's discretization loop (numerics/ad/ad_utils.py:281-308) dealt out to two ranks by subdomain
+    (porepy_amd.md_sharding), each rank discretizing its share through the rebound ``pp.Mpfa`` and one exchange of the
+    stored matrices: on every rank the model's solution and last Jacobian are BITWISE those of the serial loop, and
+    the device calls are split between the ranks.  (Network of 16 fractures: the model set-up of the reference, not
+    the discretization, is what takes the time here.)"""
+    env = oracle.ref_env(extra_last=[ROOT])
+    if env is None:
+        pytest.skip("reference PorePy not present")
+    env.update({"PFV_DROPIN_LIBRARY": "emulation", "C5_FRACTURES": "16", "C5_N_SIDE": "10", "C5_MAX_EXTENT": "6",
+                "OMP_NUM_THREADS": "2"})
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tests", "_dropin_c5_script.py"), "--sharded"],
+                       env=env, cwd="/tmp", capture_output=True, text=True, timeout=1500)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, r.stderr[-3000:]
+    out = json.loads(line[-1][7:])
+    assert out["world"] == 2 and out["fractures"] == 16
+    ranks = out["ranks"]
+    assert all(x["same"] for x in ranks)
+    total = ranks[0]["device_calls_serial"]
+    assert total > 40 and sum(x["device_calls_here"] for x in ranks) == total
+    assert all(0 < x["device_calls_here"] < total for x in ranks)
+    first = ranks[0]["stats"]["plans"][0]
+    # the 3-D grid's two interaction-region jobs (Darcy, Fourier) bound the speed-up of this loop: one on each rank
+    assert 1.5 < first["bound_total_over_largest_job"] < 4.0 and first["speedup_by_cost_model"] > 1.5
+    assert all(x["stats"]["matrix_bytes_sent"] > 0 for x in ranks)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_merged_operator_parse_and_flux_products_on_the_device(variant):
     """``MergedOperator.parse`` (numerics/ad/ad_utils.py:597-663) and the matrix products of the flux
     expression formed by ``porepy_amd.DeviceCsr`` on the reference's mixed-dimensional model.  The device concatenation
