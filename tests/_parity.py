@@ -627,6 +627,43 @@ def check_mpsa_partial_case(lib, name: str):
         assert np.array_equal(full[pa.DISCRETIZATION_MATRICES]["mech"]["stress"][rows].data, full_m["stress"][rows].data)
 
 
+def amg_filter_layout_states(lib, n=6):
+    """Strength filter of the AMG setup (amg_filter): the row layout of the previous filtering is offered again only
+    after a setup that reproduced it; a try that does not fit costs one repeat and withdraws the offer.  States of
+    ``stats()["amg_filter_layout"]``: 0 counted + scanned, 1 wrote into the kept layout, 2 tried, did not fit, redone.
+    Every solve is checked against the direct solution."""
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1, 1, 1])
+    g.compute_geometry()
+    rng = np.random.default_rng(2)
+    nc = g.num_cells
+    bf = g.get_all_boundary_faces()
+    xf = g.face_centers[0, bf]
+    dirf = bf[(xf < 1e-9) | (xf > 1 - 1e-9)]
+    bc = pa.BoundaryCondition(g, dirf, ["dir"] * dirf.size)
+    bv = np.zeros(g.num_faces)
+    bv[dirf] = g.face_centers[0, dirf]
+
+    def tensor(sc):
+        return pa.SecondOrderTensor(kxx=sc, kyy=5 * sc, kxy=0.4 * sc, kzz=0.2 * sc, kyz=0.1 * sc)
+
+    s1 = np.exp(0.5 * rng.standard_normal(nc))
+    s2 = s1 * np.exp(0.1 * rng.standard_normal(nc))
+    s3 = s1 * np.exp(1.0 * rng.standard_normal(nc))
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": tensor(s1), "bc": bc, "bc_values": bv})
+    d = pa.Mpfa("flow", library=lib)
+    states = []
+    for sc in (s1, s1, s1, s2, s3, s2, s2, s2):
+        data[pa.PARAMETERS]["flow"]["second_order_tensor"] = tensor(sc)
+        d.discretize(g, data)
+        A, b = d.assemble_matrix_rhs(g, data)
+        x, info = d.solve(g, data, source=g.cell_volumes, method="bicgstab", rtol=1e-12, precond="amg")
+        xo = spla.spsolve(A.tocsc(), b + g.cell_volumes)
+        assert info["converged"] and np.linalg.norm(x - xo) <= TOL * np.linalg.norm(xo)
+        states.append(int(d.context(g).stats()["amg_filter_layout"]))
+    assert states == [0, 0, 1, 2, 0, 0, 0, 1], states
+    return states
+
+
 def amg_preconditioner(lib, g, seed=2, hetero_sigma=0.5):
     """Aggregation-AMG-preconditioned solves against the direct solution of the same system, far fewer
     iterations than Jacobi, bitwise repeatable."""
@@ -664,6 +701,7 @@ def amg_preconditioner(lib, g, seed=2, hetero_sigma=0.5):
     # (entries of all the cycle's matrices over nnz(A): below 1 when the strength filter thins the finest level too)
     assert st["amg_levels"] >= 2 and 0.2 < st["amg_operator_complexity"] < 2.0
     assert st["amg_maps_reused"] == 0  # first hierarchy of this pattern
+    assert st["amg_filter_layout"] == 0  # (one setup so far -- the repeated solves reuse the hierarchy as it is)
     # new parameter values on the same grid: the patterns stay, the hierarchy keeps its aggregates and
     # redoes the Galerkin products only; the solve is still right and about as fast
     sc2 = sc * np.exp(0.1 * rng.standard_normal(nc))

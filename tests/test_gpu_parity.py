@@ -189,6 +189,10 @@ def test_zero_dimensional_grid(lib):
     P.check_zero_dimensional_grid(lib)
 
 
+def test_amg_filter_keeps_its_row_layout_only_after_a_setup_that_reproduced_it(lib):
+    P.amg_filter_layout_states(lib)
+
+
 def test_amg_preconditioner(lib):
     g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([12, 12, 12], [1, 1, 1])), 0.015)
     P.amg_preconditioner(lib, g)
