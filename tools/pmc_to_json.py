@@ -15,7 +15,7 @@ def short(name: str):
     """(class, variant) of a dispatch: the SpMV kernels run on every AMG level with their own template arguments --
     the variant with the most bytes per launch is the finest level's (picked below)."""
     if "k_spmv_win" in name:
-        a = name.split("k_spmv_win<")[1].split(">")[0].replace(" ", "")
+        a = name.replace("k_spmv_win_pre<", "k_spmv_win<").split("k_spmv_win<")[1].split(">")[0].replace(" ", "")
         parts = a.split(",")  # L, U, value type, epilogue
         if parts[2] == "double" and parts[3] in ("2", "3"):
             return "krylov", a
