@@ -127,6 +127,7 @@ struct pfv_ctx_impl {
   Buf<uint8_t> h_first;       // [nh] 1 if h is the side fluxes are evaluated from
   Buf<int32_t> node_fptr;     // [nn+1] segment of each node in node_sf
   Buf<int32_t> node_sf;       // [nsf] global subface ids (= face_nodes CSC positions), by (node, face)
+  Buf<int32_t> node_face;     // [nsf] face id of every entry of node_sf (= sf_face[node_sf[.]]): one load instead of two
   Buf<int32_t> sf_face;       // [nsf] face of a subface
   Buf<uint8_t> sf_ls;         // [nsf] local index of the subface within its node
   Buf<int32_t> face_nsides;   // [nf] 1 = boundary face
