@@ -150,12 +150,16 @@ def _run(pp, mdg, job: Job, slots):
 
 
 def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None, rank: int | None = None,
-                                 world: int | None = None, cost=None, exchange=None, stats: dict | None = None):
+                                 world: int | None = None, cost=None, exchange=None, stats: dict | None = None,
+                                 batch: bool = True):
     """``pp.ad.discretize_from_list`` (ad_utils.py:281-308) with the (discretization, grid) pairs dealt out to ranks.
 
     ``exchange(payload) -> list of payloads by rank`` defaults to ``torch.distributed.all_gather_object`` on
     ``group``; with ``world == 1`` the call IS the reference's loop.  ``stats`` (a dict) receives the plan summary,
-    the jobs run here and the bytes of matrices sent."""
+    the jobs run here and the bytes of matrices sent.
+    ``batch``: the subdomain jobs a rank owns for one discretization object go to its ``discretize_batch`` in one call
+    where the object has one (``porepy_amd.Mpfa``: grids of one dimension as ONE disjoint union on the device -- 52
+    fracture planes in one discretization instead of 52), in the loop's order otherwise."""
     if pp is None:
         import porepy as pp  # noqa: PLC0415  (the reference package this loop belongs to)
     if exchange is None and (world is None or rank is None):
@@ -168,17 +172,30 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
             world, rank = 1, 0
     pl = plan(discretizations, world, cost, is_interface=lambda g: isinstance(g, pp.MortarGrid))
     mine: dict = {}
-    for i, job in enumerate(pl.jobs):
-        if job.owner != rank:
-            continue
-        slots = _matrix_slots(pp, mdg, job)
-        before = _snapshot(pp, slots)
-        _run(pp, mdg, job, slots)
+    own = [i for i, job in enumerate(pl.jobs) if job.owner == rank]
+    slots_of = {i: _matrix_slots(pp, mdg, pl.jobs[i]) for i in own}
+    before_of = {i: _snapshot(pp, slots_of[i]) for i in own}
+    done = set()
+    batches = 0
+    if batch:
+        by_discr: dict = {}
+        for i in own:
+            job = pl.jobs[i]
+            if not job.is_interface and hasattr(job.discr, "discretize_batch"):
+                by_discr.setdefault(id(job.discr), (job.discr, []))[1].append(i)
+        for discr, idx in by_discr.values():
+            if len(idx) > 1:
+                discr.discretize_batch([(pl.jobs[i].grid, slots_of[i][0]) for i in idx])
+                done.update(idx)
+                batches += 1
+    for i in own:
+        if i not in done:
+            _run(pp, mdg, pl.jobs[i], slots_of[i])
         out = []
-        for s, d in enumerate(slots):
+        for s, d in enumerate(slots_of[i]):
             for kw, md in d.get(pp.DISCRETIZATION_MATRICES, {}).items():
                 for name, v in md.items():
-                    if before.get((s, kw, name), _ABSENT) is not v:
+                    if before_of[i].get((s, kw, name), _ABSENT) is not v:
                         out.append((s, kw, name, _host_value(v)))
         mine[i] = out
     sent = 0
@@ -210,6 +227,8 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
         stats["plan"] = pl.summary()
         stats.setdefault("plans", []).append(stats["plan"])
         stats["jobs_run_here"] = stats.get("jobs_run_here", 0) + len(mine)
+        stats["batch_calls"] = stats.get("batch_calls", 0) + batches
+        stats["jobs_in_batches"] = stats.get("jobs_in_batches", 0) + len(done)
         stats["matrix_bytes_sent"] = stats.get("matrix_bytes_sent", 0) + int(sent)
         stats["rank"] = rank
     return pl
@@ -217,17 +236,23 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
 
 @contextlib.contextmanager
 def sharded_discretization(pp, group=None, rank: int | None = None, world: int | None = None, cost=None,
-                           exchange=None, stats: dict | None = None):
+                           exchange=None, stats: dict | None = None, batch: bool = True):
     """Rebind ``pp.ad.discretize_from_list`` (the loop every model discretizes through: equation_system.py:1559,
     solution_strategy.py:995 / 1014, operators.py:487) to the sharded loop inside the ``with`` block."""
     orig = pp.ad.discretize_from_list
 
     def sharded(discretizations, mdg):
         return discretize_from_list_sharded(discretizations, mdg, pp=pp, group=group, rank=rank, world=world,
-                                            cost=cost, exchange=exchange, stats=stats)
+                                            cost=cost, exchange=exchange, stats=stats, batch=batch)
 
     pp.ad.discretize_from_list = sharded
     try:
         yield sharded
     finally:
         pp.ad.discretize_from_list = orig
+
+
+def batched_discretization(pp, stats: dict | None = None):
+    """One process: the reference's loop with the subdomain jobs of every discretization object handed to its
+    ``discretize_batch`` (``sharded_discretization`` with one rank)."""
+    return sharded_discretization(pp, rank=0, world=1, stats=stats, batch=True)

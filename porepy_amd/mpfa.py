@@ -573,6 +573,151 @@ class Mpfa:
         pd["active_cells"] = active_cells
         pd["active_faces"] = active_faces
 
+    # ---- many small grids at once -------------------------------------------------------------------------------
+    def _batchable(self, sd, data: dict):
+        """eta if (sd, data) can join a disjoint union -- plain inputs: full discretization, conditions per face, one
+        continuity point, no periodic faces, no ``partition_arguments`` -- else None (the single-grid path takes it)."""
+        if sd.dim < 2 or self.lazy or hasattr(sd, "periodic_face_map"):
+            return None
+        pd = data[PARAMETERS][self.keyword]
+        if any(pd.get(k) is not None for k in ("specified_cells", "specified_faces", "specified_nodes")):
+            return None
+        if pd.get("update_discretization") or pd.get("partition_arguments") or pd.get("hip_rebuild_topology"):
+            return None
+        vdim = pd.get("ambient_dimension", sd.dim)
+        if vdim != sd.dim and not (sd.dim == 2 and vdim == 3):
+            return None
+        if np.asarray(pd["bc"].is_dir).size != sd.num_faces:
+            return None
+        eta = pd.get("mpfa_eta", None)
+        if eta is None:
+            return float(determine_eta(sd))
+        return float(np.asarray(eta).ravel()[0]) if np.asarray(eta).size == 1 else None
+
+    def discretize_batch(self, items) -> dict:
+        """``discretize(sd, data)`` for every pair of ``items`` -- the grids of a mixed-dimensional model (52 fracture
+        planes of a few dozen cells each: numerics/ad/ad_utils.py:288-308 calls them one by one) -- with all grids of
+        one dimension and one continuity point discretized as ONE disjoint union on the device: one upload, one
+        topology + symbolic phase, one launch of each kernel over all interaction regions, one fetch per matrix,
+        instead of a handle and ~40 launches of ~5 us per grid.  The interaction regions of different grids share
+        nothing, so every block of the union's matrices is the matrix of its grid (same kernels, same inputs per
+        region: the same bits as the single-grid path).  Pairs with special inputs go through ``discretize``.
+        Returns {"unions": number of device discretizations, "batched": grids in them, "single": grids taken alone}."""
+        import scipy.sparse as sps
+
+        groups: dict = {}
+        single = []
+        for sd, data in items:
+            eta = self._batchable(sd, data)
+            if eta is None:
+                single.append((sd, data))
+            else:
+                groups.setdefault((int(sd.dim), eta), []).append((sd, data))
+        stats = {"unions": 0, "batched": 0, "single": 0}
+        for (dim, eta), members in groups.items():
+            if len(members) < 2:
+                single.extend(members)
+                continue
+            raws, planes, kvals, flags, robin = [], [], [], [], []
+            for sd, data in members:
+                pd = data[PARAMETERS][self.keyword]
+                note_ignored_parameters(pd, self.keyword)
+                raw = grid_to_raw(sd)
+                T = None
+                if dim == 2:
+                    T = plane_basis(raw["nodes"])
+                    if T is not None:
+                        for k in ("nodes", "face_normals", "face_centers", "cell_centers"):
+                            loc = np.zeros_like(raw[k])
+                            loc[:2] = T @ raw[k]
+                            raw[k] = loc
+                kv = np.asarray(pd["second_order_tensor"].values, dtype=float)
+                if T is not None:
+                    k2 = np.einsum("ia,abn,jb->ijn", T, kv, T)
+                    kv = np.zeros_like(kv)
+                    kv[:2, :2] = k2
+                    kv[2, 2] = 1.0
+                raws.append(raw)
+                planes.append(T)
+                kvals.append(kv)
+                flags.append(bc_flags(pd["bc"]))
+                robin.append(np.asarray(pd["bc"].robin_weight, dtype=float))
+            nn = np.cumsum([0] + [r["nodes"].shape[1] for r in raws])
+            nf = np.cumsum([0] + [r["face_centers"].shape[1] for r in raws])
+            nc = np.cumsum([0] + [r["cell_centers"].shape[1] for r in raws])
+
+            def cat_csc(ptr_key, idx_key, row_offsets):
+                ptr, idx, base = [np.zeros(1, dtype=np.int64)], [], 0
+                for r, off in zip(raws, row_offsets):
+                    ptr.append(np.asarray(r[ptr_key][1:], dtype=np.int64) + base)
+                    idx.append(np.asarray(r[idx_key], dtype=np.int64) + off)
+                    base += int(r[ptr_key][-1])
+                return np.concatenate(ptr).astype(np.int32), np.concatenate(idx).astype(np.int32)
+
+            cf_ptr, cf_idx = cat_csc("cf_indptr", "cf_indices", nf[:-1])
+            fn_ptr, fn_idx = cat_csc("fn_indptr", "fn_indices", nn[:-1])
+            union = {"dim": dim, "name": "disjoint union of %d grids" % len(members),
+                     "cf_indptr": cf_ptr, "cf_indices": cf_idx, "cf_sign": np.concatenate([r["cf_sign"] for r in raws]),
+                     "fn_indptr": fn_ptr, "fn_indices": fn_idx,
+                     "fracture_faces": np.concatenate([r["fracture_faces"] for r in raws])}
+            for k in ("nodes", "face_normals", "face_centers", "cell_centers"):
+                union[k] = np.ascontiguousarray(np.concatenate([r[k] for r in raws], axis=1))
+            for k in ("face_areas", "cell_volumes"):
+                union[k] = np.ascontiguousarray(np.concatenate([r[k] for r in raws]))
+            ctx = _lib.Context(self.device, self._library)
+            try:
+                ctx.set_grid(union)
+                ctx.set_params(np.ascontiguousarray(np.concatenate(kvals, axis=2)), np.concatenate(flags),
+                               np.concatenate(robin), float(eta), None)
+                try:
+                    ctx.discretize(rebuild_topology=False)
+                except _lib.PorefvError as e:
+                    if e.status == 1:
+                        raise ValueError("Error in inversion of local linear systems") from e
+                    if e.status == 2:
+                        raise AssertionError(e.message) from e
+                    raise
+                whole = {name: ctx.matrix(which) for name, which in _KEYS}
+                # A = div @ flux of the union, on the device; its diagonal blocks are the systems of the grids
+                ctx.assemble(np.zeros(int(nf[-1])), None, None)
+                A_union = ctx.matrix(_lib.MAT_SYSTEM)
+            finally:
+                ctx.close()
+            for g, (sd, data) in enumerate(members):
+                pd = data[PARAMETERS][self.keyword]
+                md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
+                f0, f1, c0, c1 = int(nf[g]), int(nf[g + 1]), int(nc[g]), int(nc[g + 1])
+                vdim = pd.get("ambient_dimension", sd.dim)
+                T = planes[g]
+                lift = None
+                if sd.dim == 2 and vdim == 3:
+                    basis = T if T is not None else np.eye(2, 3)
+                    lift = sps.kron(sps.identity(sd.num_cells, format="csr"), sps.csr_matrix(basis), format="csr")
+                elif sd.dim == 2 and T is not None:
+                    lift = planar_source_map(sd, T)
+                cols = {"flux": (c0, c1), "bound_flux": (f0, f1), "bound_pressure_cell": (c0, c1),
+                        "bound_pressure_face": (f0, f1), "vector_source": (dim * c0, dim * c1),
+                        "bound_pressure_vector_source": (dim * c0, dim * c1)}
+                for name, _ in _KEYS:
+                    a, b = cols[name]
+                    new = sps.csr_matrix(whole[name][f0:f1][:, a:b])
+                    if lift is not None and "vector_source" in name:
+                        new = (new @ lift).tocsr()
+                    new.sort_indices()
+                    md[name] = new
+                pd["active_cells"] = np.arange(sd.num_cells)
+                pd["active_faces"] = np.arange(sd.num_faces)
+                self.invalidate(sd)  # (no handle of its own holds this grid's discretization:
+                A_g = sps.csr_matrix(A_union[c0:c1][:, c0:c1])  # assemble_matrix_rhs goes the way of a grid in pieces)
+                A_g.sort_indices()
+                self._split[id(sd)] = (sd, A_g)
+            stats["unions"] += 1
+            stats["batched"] += len(members)
+        for sd, data in single:
+            self.discretize(sd, data)
+            stats["single"] += 1
+        return stats
+
     def update_discretization(self, sd, data: dict) -> None:
         """Rediscretize around ``data["update_discretization"]["modified_cells" / "modified_faces"]``
         and keep every other row (mpfa.py:510-590 via _fvutils.partial_update_discretization,
@@ -718,6 +863,15 @@ def as_porepy_discretization(device: int = 0, library=None):
             if sd.dim < 2:
                 return super().discretize(sd, data)  # 1-D -> Tpfa, 0-D -> empty, as upstream
             return self._hip.discretize(sd, data)
+
+        def discretize_batch(self, items):
+            """All (sd, data) pairs of one loop over a mixed-dimensional grid: grids of dimension >= 2 as disjoint
+            unions on the device (``porepy_amd.Mpfa.discretize_batch``), the rest as upstream."""
+            items = list(items)
+            for sd, data in items:
+                if sd.dim < 2:
+                    super().discretize(sd, data)
+            return self._hip.discretize_batch([(sd, data) for sd, data in items if sd.dim >= 2])
 
         def update_discretization(self, sd, data):
             if sd.dim < 2:

@@ -156,6 +156,19 @@ def rebind():
         return orig(self, sd, data)
 
     HipMpfa.discretize = counting
+    orig_batch = HipMpfa.discretize_batch
+
+    def counting_batch(self, items):
+        items = list(items)
+        st = orig_batch(self, items)
+        calls["batch_calls"] = calls.get("batch_calls", 0) + 1
+        calls["grids_in_batch_calls"] = calls.get("grids_in_batch_calls", 0) + len(items)
+        calls["device_unions"] = calls.get("device_unions", 0) + st["unions"]
+        calls["grids_in_unions"] = calls.get("grids_in_unions", 0) + st["batched"]
+        calls["grids_alone"] = calls.get("grids_alone", 0) + st["single"]
+        return st
+
+    HipMpfa.discretize_batch = counting_batch
     pp.Mpfa = HipMpfa
     return calls
 
@@ -191,11 +204,16 @@ def save_first_jacobian():
 def main_serial():
     ref = run()
     calls = rebind()
-    both = run(HipSolveModel, "hip_gmres", {"precond": "block", "rtol": 1e-13, "restart": 80})
+    # the subdomain loop hands all grids of a discretization object to its discretize_batch: the 52 fracture planes
+    # are ONE disjoint union on the device per keyword (the 3-D grid is alone in its dimension: single-grid path)
+    loop_stats = {}
+    with md_sharding.batched_discretization(pp, stats=loop_stats):
+        both = run(HipSolveModel, "hip_gmres", {"precond": "block", "rtol": 1e-13, "restart": 80})
     nrm = np.linalg.norm(ref["x"])
     out = {
         "fractures": ref["dims"].get(2, 0), "lines": ref["dims"].get(1, 0), "points": ref["dims"].get(0, 0),
         "interfaces": ref["n_intf"], "cells": ref["cells"], "dofs": int(ref["x"].size), "device_calls": calls,
+        "loop": {k: loop_stats.get(k) for k in ("calls", "batch_calls", "jobs_in_batches")},
         "x_rel_err": float(np.linalg.norm(both["x"] - ref["x"]) / nrm),
         "T_rel_err": float(np.linalg.norm(both["T"] - ref["T"]) / np.linalg.norm(ref["T"])),
         "p_rel_err": float(np.linalg.norm(both["p"] - ref["p"]) / np.linalg.norm(ref["p"])),
@@ -222,11 +240,12 @@ def main_sharded():
     stats = {}
     with md_sharding.sharded_discretization(pp, stats=stats):
         sharded = run()
-    n_here = sum(calls.values())
+    n_here = sum(v for k, v in calls.items() if ":" in k) + calls.get("grids_in_batch_calls", 0)
     same = bool(np.array_equal(serial["x"], sharded["x"]) and (serial["A"] != sharded["A"]).nnz == 0)
     gathered = [None] * world
     dist.all_gather_object(gathered, {"rank": rank, "same": same, "device_calls_here": n_here,
-                                      "device_calls_serial": n_serial, "stats": stats})
+                                      "device_calls_serial": n_serial, "stats": stats,
+                                      "device_unions": calls.get("device_unions", 0)})
     if rank == 0:
         out = {"world": world, "ranks": gathered, "dofs": int(serial["x"].size),
                "fractures": serial["dims"].get(2, 0), "library": str(P.dropin_library()._name)}

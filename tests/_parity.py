@@ -1881,3 +1881,73 @@ def sliver_refinement(lib):
     assert off[0] > 5e-9 and off[1] > 5e-9, off  # the fixtures do exercise the path
     assert on[0] < SLIVER_TOL and on[1] < SLIVER_TOL and max(on) < 0.05 * min(off), (on, off)
     return off, on
+
+
+def _geo2(g):
+    g.compute_geometry()
+    return g
+
+
+def batch_matches_single(lib):
+    """``Mpfa.discretize_batch``: grids of a mixed-dimensional model discretized as disjoint unions (one device
+    discretization per dimension and continuity point) leave, grid by grid, the BITS of the single-grid path -- planes
+    tilted differently in 3-D with a 3-D vector source, a plane with the default ambient dimension, Cartesian and
+    simplex grids (different continuity points: separate unions), a grid with conditions per sub-face (taken alone)."""
+    import scipy.sparse as sps
+
+    rng = np.random.default_rng(5)
+
+    def tilt(g, axis, angle, shift):
+        c, s_ = np.cos(angle), np.sin(angle)
+        R = {0: np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]]), 1: np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]])}[axis]
+        g.nodes = R @ g.nodes + np.asarray(shift, float)[:, None]
+        g.compute_geometry()
+        return g
+
+    def bc_for(g, sub=False):
+        bf = g.get_all_boundary_faces()
+        lo = bf[np.argsort(g.face_centers[0, bf] + 0.37 * g.face_centers[1, bf] + 0.11 * g.face_centers[2, bf])[: max(2, bf.size // 3)]]
+        return pa.BoundaryCondition(g, lo, ["dir"] * lo.size)
+
+    def tensor(g, full3=False):
+        nc = g.num_cells
+        sc = np.exp(0.4 * rng.standard_normal(nc))
+        if g.dim == 3 or full3:
+            return pa.SecondOrderTensor(kxx=sc, kyy=3 * sc, kzz=0.5 * sc, kxy=0.3 * sc, kyz=0.1 * sc, kxz=0.05 * sc)
+        return pa.SecondOrderTensor(kxx=sc, kyy=3 * sc, kxy=0.3 * sc)
+
+    grids = [
+        (tilt(_geo2(pa.CartGrid([5, 4], [1.0, 1.0])), 0, 0.7, [0.1, 0.2, 0.3]), {"ambient_dimension": 3}, True),
+        (tilt(_geo2(pa.CartGrid([3, 6], [0.5, 1.0])), 1, -0.4, [1.0, 0.0, 0.2]), {"ambient_dimension": 3}, True),
+        (_geo2(pa.CartGrid([4, 4], [1.0, 2.0])), {}, False),
+        (tilt(_geo2(pa.StructuredTriangleGrid([3, 3], [1.0, 1.0])), 0, 1.1, [0.0, 0.5, 0.0]), {"ambient_dimension": 3}, True),
+        (_geo2(pa.StructuredTriangleGrid([4, 2], [2.0, 1.0])), {}, False),
+        (_geo2(pa.CartGrid([3, 3, 2], [1.0, 1.0, 1.0])), {}, False),
+        (_geo2(pa.CartGrid([2, 3, 3], [1.0, 2.0, 1.0])), {}, False),
+        (pa.perturb_interior_nodes(_geo2(pa.StructuredTetrahedralGrid([2, 2, 2], [1.0, 1.0, 1.0])), 0.05), {}, False),
+    ]
+    items_b, items_s = [], []
+    for g, extra, full3 in grids:
+        K = tensor(g, full3)
+        bc = bc_for(g)
+        for items in (items_b, items_s):
+            items.append((g, pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc,
+                                                             "bc_values": np.zeros(g.num_faces), **extra})))
+    db, ds = pa.Mpfa("flow", library=lib), pa.Mpfa("flow", library=lib)
+    stats = db.discretize_batch(items_b)
+    # unions: 2-D Cartesian (eta 0: 3 grids), 2-D triangles (eta 1/3: 2), 3-D Cartesian (2); the tetrahedral grid is alone
+    assert stats == {"unions": 3, "batched": 7, "single": 1}, stats
+    for (g, dat_b), (_, dat_s) in zip(items_b, items_s):
+        ds.discretize(g, dat_s)
+        mb, ms = dat_b[pa.DISCRETIZATION_MATRICES]["flow"], dat_s[pa.DISCRETIZATION_MATRICES]["flow"]
+        for k in ALL_KEYS:
+            a, b = sps.csr_matrix(mb[k]), sps.csr_matrix(ms[k])
+            assert a.shape == b.shape, (g.name, k, a.shape, b.shape)
+            assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices), (g.name, k)
+            assert np.array_equal(a.data, b.data), (g.name, k, float(abs(a - b).max()))
+        assert np.array_equal(dat_b[pa.PARAMETERS]["flow"]["active_faces"], np.arange(g.num_faces))
+        # the system of a grid that was part of a union assembles like any other
+        Ab, bb = db.assemble_matrix_rhs(g, dat_b)
+        As, bs_ = ds.assemble_matrix_rhs(g, dat_s)
+        assert rel_max_err(Ab, As) < 1e-14 and np.allclose(bb, bs_, rtol=0, atol=1e-14)
+    return stats

@@ -189,6 +189,10 @@ def test_zero_dimensional_grid(lib):
     P.check_zero_dimensional_grid(lib)
 
 
+def test_grids_discretized_as_disjoint_unions_leave_the_bits_of_the_single_grid_path(lib):
+    P.batch_matches_single(lib)
+
+
 def test_amg_filter_keeps_its_row_layout_only_after_a_setup_that_reproduced_it(lib):
     P.amg_filter_layout_states(lib)
 

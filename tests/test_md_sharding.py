@@ -158,3 +158,29 @@ def test_rebind_context_restores_the_reference_loop():
         pp.ad.discretize_from_list(discr, mdg)
     assert pp.ad.discretize_from_list is orig and not calls
     assert len(flat(mdg)) == len(flat(mdg)) > 0
+
+
+def test_jobs_of_one_discretization_object_go_to_its_batch_entry():
+    class BatchMpfa(Mpfa):
+        def __init__(self, keyword):
+            super().__init__(keyword)
+            self.batches = []
+
+        def discretize_batch(self, items):
+            items = list(items)
+            self.batches.append([sd.name for sd, _ in items])
+            for sd, data in items:
+                Mpfa.discretize(self, sd, data)
+
+    pp = fake_pp()
+    mdg0, discr0 = make()
+    S.discretize_from_list_sharded(discr0, mdg0, pp=pp, rank=0, world=1, batch=False)
+    mdg, _ = make()
+    flow, fourier, coupling = BatchMpfa("flow"), BatchMpfa("fourier"), Coupling()
+    discr = {flow: [mdg.g3, *mdg.fr], fourier: [mdg.g3, *mdg.fr], GradP(): [mdg.g3], coupling: list(mdg.intf)}
+    stats = {}
+    S.discretize_from_list_sharded(discr, mdg, pp=pp, rank=0, world=1, stats=stats)
+    assert flow.batches == [[g.name for g in [mdg.g3, *mdg.fr]]] and len(fourier.batches) == 1
+    assert stats["batch_calls"] == 2 and stats["jobs_in_batches"] == 26 and len(coupling.ran) == 12
+    a, b = flat(mdg0), flat(mdg)
+    assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)

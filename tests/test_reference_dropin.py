@@ -124,8 +124,11 @@ def test_c5_thermo_hydro_model_on_a_52_fracture_network(variant):
     out = run_script("_dropin_c5_script.py", variant, 1500)
     assert (out["fractures"], out["lines"], out["points"], out["interfaces"]) == (52, 114, 23, 385)
     assert out["dofs"] == 21360
+    # the subdomain loop runs through md_sharding.batched_discretization: per keyword (Darcy, Fourier) the 52 fracture
+    # planes are ONE disjoint union on the device, the 3-D grid -- alone in its dimension -- takes the single-grid path
     c = out["device_calls"]
-    assert c["flow:3"] >= 1 and c["flow:2"] >= 52 and c["fourier_discretization:2"] >= 52
+    assert c["batch_calls"] == 2 and c["device_unions"] == 2 and c["grids_in_unions"] == 104 and c["grids_alone"] == 2
+    assert out["loop"]["jobs_in_batches"] == 380  # (1-D and 0-D grids included: the class hands them on as upstream)
     assert out["T_range"][1] - out["T_range"][0] > 1.0
     assert out["hip_linear_solves"] >= 3 and out["hip_solver_blocks"] == 5
     assert out["hip_solver_max_iterations"] <= 120 and out["hip_solver_worst_true_residual"] < 1e-11
@@ -165,6 +168,8 @@ def test_c5_discretization_sharded_by_subdomain_under_gloo():
     # the 3-D grid's two interaction-region jobs (Darcy, Fourier) bound the speed-up of this loop: one on each rank
     assert 1.5 < first["bound_total_over_largest_job"] < 4.0 and first["speedup_by_cost_model"] > 1.5
     assert all(x["stats"]["matrix_bytes_sent"] > 0 for x in ranks)
+    # inside a rank the fracture planes it owns went to the device as disjoint unions
+    assert sum(x["device_unions"] for x in ranks) >= 2
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
