@@ -11,6 +11,9 @@ namespace pfv {
 static int rccl_exchange_halo(void* user, double* d_x, void* stream);  // rccl_hooks.inc
 }
 #include "topology.inc"
+#ifndef PFV_EMULATE
+#include "gj_mfma.inc"
+#endif
 #include "mpfa_numeric.inc"
 #include "linalg.inc"
 #include "reorder.inc"

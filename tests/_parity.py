@@ -1951,3 +1951,36 @@ def batch_matches_single(lib):
         As, bs_ = ds.assemble_matrix_rhs(g, dat_s)
         assert rel_max_err(Ab, As) < 1e-14 and np.allclose(bb, bs_, rtol=0, atol=1e-14)
     return stats
+
+
+def matrix_core_elimination_matches(lib):
+    """PFV_NODE_GJ=4: the interaction regions with 32 < n <= 48 sub-faces eliminate on the FP64 matrix cores
+    (csrc/gj_mfma.inc: blocked by 4 pivot columns, 9 v_mfma_f64_16x16x4 per panel) -- kept as a measured alternative
+    to the lane-grid elimination.  Same inverse up to rounding: all six matrices agree to 1e-11 of the
+    largest entry on a perturbed tetrahedral grid whose interior nodes have n = 36."""
+    g = pa.StructuredTetrahedralGrid([5, 5, 5], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.04)
+    nc = g.num_cells
+    sc = np.exp(0.5 * np.random.default_rng(3).standard_normal(nc))
+    K = pa.SecondOrderTensor(kxx=sc, kyy=4 * sc, kzz=0.3 * sc, kxy=0.3 * sc, kyz=0.1 * sc, kxz=0.05 * sc)
+    bf = g.get_all_boundary_faces()
+    dirf = bf[g.face_centers[0, bf] < 1e-9]
+    bc = pa.BoundaryCondition(g, dirf, ["dir"] * dirf.size)
+    out = {}
+    for mode in ("3", "4"):
+        os.environ["PFV_NODE_GJ"] = mode
+        try:
+            data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": np.zeros(g.num_faces)})
+            d = pa.Mpfa("flow", library=lib)
+            d.discretize(g, data)
+            out[mode] = {k: data[pa.DISCRETIZATION_MATRICES]["flow"][k].tocsr() for k in ALL_KEYS}
+        finally:
+            del os.environ["PFV_NODE_GJ"]
+    worst = 0.0
+    for k in ALL_KEYS:
+        a, b = out["3"][k], out["4"][k]
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices), k
+        worst = max(worst, float(np.abs(a.data - b.data).max() / np.abs(a.data).max()))
+    assert worst < 1e-11, worst
+    return worst

@@ -189,6 +189,11 @@ def test_zero_dimensional_grid(lib):
     P.check_zero_dimensional_grid(lib)
 
 
+def test_elimination_on_the_fp64_matrix_cores_gives_the_same_matrices(lib):
+    worst = P.matrix_core_elimination_matches(lib)
+    assert worst > 0.0  # (a different summation order: if the two runs agree to the bit the switch did nothing)
+
+
 def test_grids_discretized_as_disjoint_unions_leave_the_bits_of_the_single_grid_path(lib):
     P.batch_matches_single(lib)
 
