@@ -1984,3 +1984,33 @@ def matrix_core_elimination_matches(lib):
         worst = max(worst, float(np.abs(a.data - b.data).max() / np.abs(a.data).max()))
     assert worst < 1e-11, worst
     return worst
+
+
+def batch_hands_special_inputs_to_the_single_grid_path(lib):
+    """A pair with a partial specification, or with a per-sub-face continuity point, is not laid into a union: it goes
+    through ``discretize`` as if called alone; the others still share one device discretization."""
+    def grid(nx, ny):
+        g = pa.CartGrid([nx, ny], [1.0, 1.0])
+        g.compute_geometry()
+        return g
+
+    def data_for(g, **extra):
+        bf = g.get_all_boundary_faces()
+        bc = pa.BoundaryCondition(g, bf[:4], ["dir"] * 4)
+        K = pa.SecondOrderTensor(kxx=np.linspace(1.0, 2.0, g.num_cells), kyy=np.full(g.num_cells, 3.0))
+        return pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc, "bc_values": np.zeros(g.num_faces), **extra})
+
+    gs = [grid(4, 3), grid(3, 3), grid(5, 2), grid(4, 4)]
+    extras = [{}, {}, {"specified_cells": np.array([0, 1])}, {"mpfa_eta": np.full(int(gs[3].face_nodes.nnz), 0.1)}]
+    items = [(g, data_for(g, **e)) for g, e in zip(gs, extras)]
+    d = pa.Mpfa("flow", library=lib)
+    stats = d.discretize_batch(items)
+    assert stats == {"unions": 1, "batched": 2, "single": 2}, stats
+    for (g, dat), e in zip(items, extras):
+        ref = data_for(g, **e)
+        pa.Mpfa("flow", library=lib).discretize(g, ref)
+        for k in ALL_KEYS:
+            a, b = dat[pa.DISCRETIZATION_MATRICES]["flow"][k].tocsr(), ref[pa.DISCRETIZATION_MATRICES]["flow"][k].tocsr()
+            assert a.shape == b.shape and abs(a - b).max() == 0.0, (g.num_cells, k)
+    assert items[2][1][pa.PARAMETERS]["flow"]["active_faces"].size < gs[2].num_faces  # (the partial one stayed partial)
+    return stats

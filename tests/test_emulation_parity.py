@@ -205,6 +205,10 @@ def test_grids_discretized_as_disjoint_unions_leave_the_bits_of_the_single_grid_
     P.batch_matches_single(lib)
 
 
+def test_batch_hands_special_inputs_to_the_single_grid_path(lib):
+    P.batch_hands_special_inputs_to_the_single_grid_path(lib)
+
+
 def test_amg_filter_keeps_its_row_layout_only_after_a_setup_that_reproduced_it(lib):
     P.amg_filter_layout_states(lib)
 
