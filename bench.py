@@ -892,7 +892,12 @@ def main():
                                            "generic anisotropic inputs; where the reference's sparse products drop exact zeros, "
                                            "what is stored outside its pattern is < 1e-12 of the row maximum)",
                        "iterations": info["iterations"], "converged": info["converged"],
-                       "true_rel_residual": res_true, "field_error": field,
+                       "true_rel_residual": res_true,
+                       # (N > 1: the residual the sharded loop stopped on -- |b - A x| over all ranks by the recursion,
+                       # re-evaluated from the definition every check interval; no rank holds the whole system)
+                       "rel_residual_of_the_sharded_loop": (float(info["rel_residual"]) if res_true is None and isinstance(info, dict)
+                                                            and info.get("rel_residual") is not None else None),
+                       "field_error": field,
                        "global_cells": ncells_total,
                        "transport": (info.get("transport") if isinstance(info, dict) else None),
                        "parallelism": "1 GPU" if world == 1 else
