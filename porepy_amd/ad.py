@@ -54,20 +54,66 @@ def evaluate_on_device(operator, equation_system, context: "_lib.Context", state
     return res
 
 
-def assemble_on_device(equation_system, context: "_lib.Context", state=None, equations=None):
+import contextlib
+
+
+@contextlib.contextmanager
+def device_matrix_leaves(context: "_lib.Context"):
+    """Inside the block the discretization-matrix leaves of the operator trees (``MergedOperator.parse``,
+    numerics/ad/ad_utils.py:597-663: the block-diagonal concatenation of the subdomains' matrices) are formed ON THE
+    DEVICE as ``DeviceCsr`` -- from lazily kept device matrices without a host copy (``Mpfa(lazy=True)``), from host
+    matrices by an upload that is remembered per matrix object.  Products with them (value: device SpMV, Jacobian:
+    device product) then never see a host copy of the discretization."""
+    import porepy as pp
+    from .device_csr import block_diag
+
+    cls = pp.ad.MergedOperator
+    orig = cls.parse
+
+    def parse(self, mdg):
+        if len(self.domains) == 0:
+            return orig(self, mdg)
+        mats = []
+        for grid in self.domains:
+            if isinstance(grid, pp.MortarGrid):
+                data = mdg.interface_data(grid)
+            elif isinstance(grid, pp.Grid):
+                data = mdg.subdomain_data(grid)
+            else:
+                return orig(self, mdg)
+            md = data[pp.DISCRETIZATION_MATRICES][self._physics_key]
+            m = md[getattr(self._discr, self._discretization_matrix_key + "_matrix_key")]
+            if self._inner_physics_key is not None:
+                m = m[self._inner_physics_key]
+            if isinstance(m, np.ndarray):
+                return orig(self, mdg)
+            mats.append(m)
+        return block_diag(mats, context)
+
+    cls.parse = parse
+    try:
+        yield
+    finally:
+        cls.parse = orig
+
+
+def assemble_on_device(equation_system, context: "_lib.Context", state=None, equations=None, device_leaves: bool = False):
     """``EquationSystem.assemble`` with the Jacobian formed and kept on the device: returns ``(J, b)`` with ``J`` a
     ``DeviceCsr`` (all equations stacked in the order of ``equation_system.equations``, all variables) and
     ``b = -residual`` a numpy vector, i.e. the linear system ``J dx = b`` of a Newton iteration
-    (equation_system.py:1579-1700)."""
+    (equation_system.py:1579-1700).  ``device_leaves``: the discretization matrices enter the trees as ``DeviceCsr`` too
+    (:func:`device_matrix_leaves`): values by device SpMV -- equal to the host products to rounding, not to the bit."""
     names = list(equation_system.equations) if equations is None else list(equations)
     base = device_ad_base(equation_system, context, state)
     vals, jacs = [], []
+    leaves = device_matrix_leaves(context) if device_leaves else contextlib.nullcontext()
     try:
-        for name in names:
-            ad = evaluate_on_device(equation_system.equations[name], equation_system, context, ad_base=base)
-            if ad.val.size:
-                vals.append(ad.val)
-                jacs.append(ad.jac)
+        with leaves:
+            for name in names:
+                ad = evaluate_on_device(equation_system.equations[name], equation_system, context, ad_base=base)
+                if ad.val.size:
+                    vals.append(ad.val)
+                    jacs.append(ad.jac)
     finally:
         equation_system._ad_parser.clear_cache()
     J = jacs[0] if len(jacs) == 1 else vstack(jacs, context)

@@ -153,6 +153,10 @@ class DeviceCsr:
             if d is not None:
                 return self.scaled(cols=d)
             return self._binary(self.ctx.lib.pfv_csr_matmul, self._c, DeviceCsr.from_any(other, self.ctx)._c)
+        if hasattr(other, "val") and hasattr(other, "jac"):
+            # a forward-mode AD array of the reference (numerics/ad/forward_mode.py:565-592: ``AdArray.__rmatmul__`` only
+            # takes scipy matrices): value by the device SpMV, Jacobian by the device product
+            return type(other)(self @ np.asarray(other.val, dtype=np.float64), self @ other.jac)
         x = np.asarray(other)
         if x.ndim != 1 or x.shape[0] != self.shape[1]:
             raise ValueError("DeviceCsr @ x expects a vector of matching length (or another DeviceCsr)")

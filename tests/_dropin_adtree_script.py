@@ -60,6 +60,15 @@ rng = np.random.default_rng(0)
 m.equation_system.set_variable_values(x * (1.0 + 0.05 * rng.random(x.size)) + 0.01 * rng.random(x.size), iterate_index=0)
 out["md_flow"] = compare(m, ctx)
 out["md_flow"]["dims"] = sorted({sd.dim for sd in m.mdg.subdomains()}, reverse=True)
+# ... and with the discretization matrices entering the trees as DeviceCsr as well (no host copy of a leaf in any product)
+A0, b0 = m.equation_system.assemble()
+J1, b1 = pa.ad.assemble_on_device(m.equation_system, ctx, device_leaves=True)
+A0 = sps.csr_matrix(A0)
+J1h = J1.to_scipy()
+out["md_flow_device_leaves"] = {
+    "jac_rel_err": float(abs(J1h - A0).max() / abs(A0).max()),
+    "rhs_rel_err": float(np.linalg.norm(np.asarray(b0) - b1) / np.linalg.norm(b0)),
+    "same_shape": bool(J1h.shape == A0.shape)}
 
 # --- the device Jacobian goes to the device solver without a host copy: Newton increment vs scipy's direct solve
 A, b = m.equation_system.assemble()

@@ -205,6 +205,10 @@ def test_operator_trees_of_the_reference_evaluated_with_device_jacobians(variant
     assert f["dims"] == [3, 2, 1] and f["dofs"] == 180 and f["equations"] == 3
     assert f["bit_identical"] is True and f["rhs_identical"] is True
     assert out["newton_increment_rel_err"] < 1e-10 and out["newton_increment_iterations"] > 0
+    # the discretization matrices entering the trees as DeviceCsr too (ad.device_matrix_leaves: MergedOperator.parse on the
+    # device, values by device SpMV): the same Jacobian, the residual to rounding
+    dl = out["md_flow_device_leaves"]
+    assert dl["same_shape"] and dl["jac_rel_err"] < 1e-15 and dl["rhs_rel_err"] < 1e-13
     t = out["thermo_hydro"]
     assert "error" not in t, t
     assert t["dofs"] == 440 and t["equations"] == 7 and t["same_nonzero_pattern"] is True and t["rhs_identical"] is True
