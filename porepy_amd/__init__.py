@@ -13,7 +13,7 @@ from .mpfa import Mpfa, as_porepy_discretization, determine_eta
 from .mpsa import Mpsa, as_porepy_mpsa
 from .biot import Biot, as_porepy_biot
 from .partial import active_indices
-from .solvers import HipLinearSolver, solve_block_system, solve_csr
+from .solvers import DeviceAssembly, HipLinearSolver, solve_block_system, solve_csr
 from .device_csr import DeviceCsr, block_diag, bmat, merged_matrix, vstack
 from . import ad
 from . import md_sharding
@@ -26,5 +26,5 @@ __all__ = [
     "StructuredTetrahedralGrid", "TetrahedralGrid", "perturb_interior_nodes", "grid_to_raw", "grid_from_raw", "Mpfa",
     "as_porepy_discretization", "determine_eta", "SecondOrderTensor", "BoundaryCondition", "Mpsa",
     "FourthOrderTensor", "BoundaryConditionVectorial",
-    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa", "DifferentiableTpfa", "as_porepy_ad_tpfa_flux", "Biot", "as_porepy_mpsa", "as_porepy_biot", "DeviceCsr", "block_diag", "bmat", "merged_matrix", "vstack", "ad", "solve_block_system", "md_sharding",
+    "initialize_data", "bc_to_raw", "bc_flags", "PARAMETERS", "DISCRETIZATION_MATRICES", "_lib", "active_indices", "HipLinearSolver", "solve_csr", "Tpfa", "DifferentiableTpfa", "as_porepy_ad_tpfa_flux", "Biot", "as_porepy_mpsa", "as_porepy_biot", "DeviceCsr", "block_diag", "bmat", "merged_matrix", "vstack", "ad", "solve_block_system", "md_sharding", "DeviceAssembly",
 ]

@@ -842,13 +842,14 @@ class Mpfa:
         return ctx.solve(method=method, rtol=rtol, maxit=maxit, x0=x0, restart=restart, precond=precond)
 
 
-def as_porepy_discretization(device: int = 0, library=None):
+def as_porepy_discretization(device: int = 0, library=None, lazy: bool = False):
     """Subclass of the reference's ``pp.Mpfa`` whose hot path runs on the MI355X.
     (``library`` is for tests that bind the host-emulation build; the product default is the
-    gfx950 library.)"""
+    gfx950 library.)  ``lazy``: the matrices stay on the device behind ``LazyCsr`` proxies (lazy.py) -- for models that
+    assemble on the device (``porepy_amd.DeviceAssembly``); whatever else reads a matrix fetches it then."""
     import porepy as pp  # the reference; absent on the GPU box
 
-    _device, _library = device, library
+    _device, _library, _lazy = device, library, bool(lazy)
     _RefMpfa = pp.Mpfa
 
     class HipMpfa(_RefMpfa):  # type: ignore[misc]
@@ -857,7 +858,7 @@ def as_porepy_discretization(device: int = 0, library=None):
             # (mpfa.py:62-63), which recurses once pp.Mpfa is rebound to this class — go to
             # its base (FVElliptic) directly
             super(_RefMpfa, self).__init__(keyword)
-            self._hip = Mpfa(keyword, _device, _library)
+            self._hip = Mpfa(keyword, _device, _library, lazy=_lazy)
 
         def discretize(self, sd, data):
             if sd.dim < 2:

@@ -223,6 +223,24 @@ class HipLinearSolver:
         opts = self.params.get("hip_solver_options", {})
         if getattr(self, "_hip_solver_context", None) is None:
             self._hip_solver_context = _lib.Context(int(opts.get("device", 0)), self.hip_library)
+        from .device_csr import DeviceCsr
+
+        if isinstance(A, DeviceCsr) and str(opts.get("precond", "jacobi")) != "block":
+            # the Jacobian was assembled on the device (DeviceAssembly): it becomes the active system of its own handle
+            # device-to-device, the solve runs there -- no host copy of the matrix at any point
+            ctx = A.as_system(np.asarray(b, dtype=float))
+            x, info = ctx.solve(method=_METHODS[solver], rtol=float(opts.get("rtol", 1e-12)),
+                                maxit=int(opts.get("maxit", 50000)), restart=int(opts.get("restart", 0)),
+                                n=A.shape[0], precond=str(opts.get("precond", "jacobi")), raise_on_fail=False)
+            if not info["converged"]:
+                raise RuntimeError(f"hip solver did not converge on the device Jacobian: {info}")
+            self.hip_solver_info = dict(info, device_jacobian=True)
+            x = np.atleast_1d(x)
+            if self._apply_schur_complement_reduction():
+                x = self.equation_system.expand_schur_complement_solution(x)
+            return x
+        if isinstance(A, DeviceCsr):
+            A = A.to_scipy()  # (the block path permutes rows and columns on the host)
         if str(opts.get("precond", "jacobi")) == "block":
             block_of, row_perm = self._hip_blocks(opts)
             # interface unknowns are condensed into the cell unknowns (solve_block_system: eliminate) once there are
@@ -310,3 +328,27 @@ class HipLinearSolver:
         except Exception:  # noqa: BLE001 - structure not exposed: fall back to the entry-wise matching
             row_perm = None
         return block, row_perm
+
+
+class DeviceAssembly:
+    """Mixin for PorePy models (before the model class, beside :class:`HipLinearSolver`): ``assemble_linear_system``
+    evaluates the model's operator trees with device-resident Jacobians AND device-resident discretization-matrix leaves
+    (``porepy_amd.ad.assemble_on_device(..., device_leaves=True)``; the reference: models/solution_strategy.py:782-827 ->
+    ``EquationSystem.assemble``, numerics/ad/equation_system.py:1579).  ``self.linear_system`` then holds
+    ``(DeviceCsr, numpy residual)``; :class:`HipLinearSolver` solves it without a host copy of the matrix.  With
+    ``pp.Mpfa = as_porepy_discretization(lazy=True)`` the discretization matrices never leave the device either:
+    discretize -> operator tree -> Jacobian -> Krylov solve, all in HBM; what crosses PCIe per Newton iteration is the
+    state vector, the residual and the increment."""
+
+    hip_library = None
+
+    def assemble_linear_system(self) -> None:
+        if self._apply_schur_complement_reduction():
+            return super().assemble_linear_system()
+        from . import ad
+
+        if getattr(self, "_hip_assembly_context", None) is None:
+            opts = self.params.get("hip_solver_options", {})
+            self._hip_assembly_context = _lib.Context(int(opts.get("device", 0)), self.hip_library)
+        J, b = ad.assemble_on_device(self.equation_system, self._hip_assembly_context, device_leaves=True)
+        self.linear_system = (J, b)

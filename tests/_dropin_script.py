@@ -74,7 +74,40 @@ pp.Mpfa = HipMpfa
 ours = run()
 # ... and with the linear solve routed to the device Krylov solver as well
 both = run(HipSolveModel, "hip_bicgstab")
+# ... and the whole Newton step in HBM: matrices kept on the device (lazy proxies), operator trees walked with device
+# Jacobians and device matrix leaves (DeviceAssembly), the device Jacobian handed to the device solver
+class AllOnDevice(pa.DeviceAssembly, pa.HipLinearSolver, Model):
+    hip_library = P.dropin_library()
+
+
+pp.Mpfa = pa.as_porepy_discretization(library=P.dropin_library(), lazy=True)
+alldev = run_alldev = None
+try:
+    params = {"times_to_export": [], "linear_solver": "hip_bicgstab", "darcy_flux_discretization": "mpfa",
+              "hip_solver_options": {"rtol": 1e-13}}
+    m = AllOnDevice(params)
+    # (the leaves stay device matrices for everything the model evaluates -- the flux post-processing, the upwind
+    # directions --, not only inside the assembly)
+    with pa.ad.device_matrix_leaves(pa.Context(0, P.dropin_library())):
+        pp.run_time_dependent_model(m, params)
+    p_dev = np.asarray(m.equation_system.get_variable_values([m.pressure_variable], time_step_index=0))
+    J_dev = m.linear_system[0]
+    sd = m.mdg.subdomains()[0]
+    md = m.mdg.subdomain_data(sd)[pp.DISCRETIZATION_MATRICES]
+    kw = [k for k in md if "flux" in md[k]][0]
+    alldev = {"p_rel_err": float(np.linalg.norm(p_dev - ref[1]) / np.linalg.norm(ref[1])),
+              "jacobian_on_device": isinstance(J_dev, pa.DeviceCsr),
+              "solved_from_device_jacobian": bool(m.hip_solver_info.get("device_jacobian")),
+              "iterations": int(m.hip_solver_info["iterations"]),
+              "flux_proxy": type(md[kw]["flux"]).__name__,
+              "flux_fetched_to_host": bool(getattr(md[kw]["flux"], "materialized", True)),
+              "A_rel_err": float(abs(J_dev.to_scipy() - ref[2]).max() / abs(ref[2]).max())}
+except Exception as e:  # noqa: BLE001
+    import traceback
+
+    alldev = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
 out = {
+    "all_on_device": alldev,
     "p_rel_err_hip_solver": float(np.linalg.norm(both[1] - ref[1]) / np.linalg.norm(ref[1])),
     "hip_solver_iterations": int(both[4]["iterations"]),
     "cells": int(ref[0]),

@@ -50,6 +50,14 @@ def test_single_phase_flow_model_with_rebound_mpfa(variant):
     assert out["A_rel_err"] < 1e-10  # (the final residual vector is round-off in both runs)
     assert out["p_rel_err_hip_solver"] < 1e-10 and out["hip_solver_iterations"] > 0
     assert abs(out["p_sum_ref"] - 8750.0) < 1e-6  # config C1 of the reference
+    # the whole Newton step in HBM under the unmodified model: matrices kept on the device (as_porepy_discretization(lazy=True)),
+    # operator trees walked with device Jacobians and device matrix leaves (DeviceAssembly), the device Jacobian solved by
+    # the device Krylov solver; the flux matrix is never fetched to the host
+    d = out["all_on_device"]
+    assert "error" not in d, d
+    assert d["jacobian_on_device"] and d["solved_from_device_jacobian"] and d["iterations"] > 0
+    assert d["flux_proxy"] == "LazyCsr" and d["flux_fetched_to_host"] is False
+    assert d["p_rel_err"] < 1e-10 and d["A_rel_err"] < 1e-12
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
