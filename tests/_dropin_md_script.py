@@ -56,7 +56,30 @@ pp.Mpfa = HipMpfa
 ours = run()
 both = run(HipSolveModel, "hip_bicgstab", {"rtol": 1e-13, "precond": "jacobi", "maxit": 20000})
 nrm = np.linalg.norm(ref["x"])
+
+
+# the whole Newton step on the device for the mixed-dimensional model as well: device-resident matrices of the 3-D and
+# 2-D grids (lazy proxies), host matrices of the 1-D grid and of the interface laws uploaded into the same block-diagonal
+# leaves, operator trees with device Jacobians, the coupled device Jacobian solved by the device Krylov solver
+class AllOnDevice(pa.DeviceAssembly, pa.HipLinearSolver, Model):
+    hip_library = P.dropin_library()
+
+
+pp.Mpfa = pa.as_porepy_discretization(library=P.dropin_library(), lazy=True)
+try:
+    with pa.ad.device_matrix_leaves(pa.Context(0, P.dropin_library())):
+        alld = run(AllOnDevice, "hip_bicgstab", {"rtol": 1e-13, "precond": "jacobi", "maxit": 20000})
+    all_on_device = {"x_rel_err": float(np.linalg.norm(alld["x"] - ref["x"]) / nrm),
+                     "jacobian_on_device": isinstance(alld["A"], pa.DeviceCsr),
+                     "solved_from_device_jacobian": bool(alld["info"].get("device_jacobian")),
+                     "iterations": int(alld["info"]["iterations"]),
+                     "A_rel_err": float(abs(alld["A"].to_scipy() - ref["A"]).max() / abs(ref["A"]).max())}
+except Exception as e:  # noqa: BLE001
+    import traceback
+
+    all_on_device = {"error": repr(e), "trace": traceback.format_exc()[-1500:]}
 out = {
+    "all_on_device": all_on_device,
     "dims": ref["dims"], "subdomains": ref["n_sub"], "interfaces": ref["n_intf"], "cells": ref["cells"],
     "mortar_cells": ref["mortar_cells"], "dofs": int(ref["x"].size),
     "device_calls_by_dim": {str(k): v for k, v in calls.items()},

@@ -99,6 +99,11 @@ def test_mixed_dimensional_model_with_rebound_mpfa_and_hip_solver(variant):
     assert out["device_calls_by_dim"]["3"] >= 1 and out["device_calls_by_dim"]["2"] >= 2
     assert out["x_rel_err"] < 1e-10 and out["A_rel_err"] < 1e-10
     assert out["x_rel_err_hip_solver"] < 1e-10 and out["hip_solver_iterations"] > 0
+    # the whole Newton step on the device for the mixed-dimensional model too (DeviceAssembly + lazy matrices + device leaves)
+    d = out["all_on_device"]
+    assert "error" not in d, d
+    assert d["jacobian_on_device"] and d["solved_from_device_jacobian"] and d["iterations"] > 0
+    assert d["x_rel_err"] < 1e-10 and d["A_rel_err"] < 1e-12
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
