@@ -279,6 +279,8 @@ class HipLinearSolver:
         None (entry-wise matching) where the model does not expose that structure, e.g. after a Schur reduction."""
         es = self.equation_system
         A = self.linear_system[0]
+        if hasattr(A, "to_scipy"):  # (a device Jacobian of DeviceAssembly: the pairing below reads entries on the host)
+            A = A.to_scipy()
         n = A.shape[0]
         block = np.full(n, -1, dtype=np.int64)
         wanted = list(opts.get("variable_order", []))
