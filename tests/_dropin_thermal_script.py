@@ -145,5 +145,20 @@ if "--save" in __import__("sys").argv:
     # right-hand side of a known answer (the converged state itself: the last Newton residual is round-off)
     np.savez_compressed(path, data=A.data, indices=A.indices, indptr=A.indptr, shape=np.array(A.shape),
                         b=A @ ref["x"], x=ref["x"], block_of=both["blocks"][0], row_perm=both["blocks"][1])
+# ... and with the Jacobian itself assembled on the device (DeviceAssembly: device Jacobians, device matrix leaves, lazy
+# matrices); the block solver reads its block description from the device matrix
+class AllOnDevice(pa.DeviceAssembly, pa.HipLinearSolver, Model):
+    hip_library = P.dropin_library()
+
+
+pp.Mpfa = pa.as_porepy_discretization(library=P.dropin_library(), lazy=True)
+try:
+    with pa.ad.device_matrix_leaves(pa.Context(0, P.dropin_library())):
+        alld = run(AllOnDevice, "hip_gmres", {"precond": "block", "rtol": 1e-13, "restart": 80})
+    out["all_on_device"] = {"x_rel_err": float(np.linalg.norm(alld["x"] - ref["x"]) / nrm),
+                            "jacobian_on_device": isinstance(alld["A"], pa.DeviceCsr),
+                            "max_iterations": int(max(s_["iterations"] for s_ in alld["solves"]))}
+except Exception as e:  # noqa: BLE001
+    out["all_on_device"] = {"error": repr(e)}
 out["library"] = str(P.dropin_library()._name)
 print("RESULT " + json.dumps(out))

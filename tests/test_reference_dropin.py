@@ -126,6 +126,10 @@ def test_thermo_hydro_mixed_dimensional_model_with_rebound_mpfa(variant):
     assert out["hip_linear_solves"] >= 4 and out["hip_rows_matched"] and out["hip_solver_blocks"] >= 10
     assert out["hip_solver_worst_true_residual"] < 1e-11
     assert out["x_rel_err_hip_solver"] < 1e-10
+    # ... and with the coupled Jacobian assembled on the device (DeviceAssembly), the block solver on top of it
+    d = out["all_on_device"]
+    assert "error" not in d, d
+    assert d["jacobian_on_device"] and d["x_rel_err"] < 1e-10 and d["max_iterations"] <= 120
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
