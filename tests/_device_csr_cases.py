@@ -235,3 +235,26 @@ def merged_subdomains(lib):
     lam = rng.random(11)
     q = flux @ p + bound_flux @ (proj @ lam)
     assert np.allclose(q, fl @ p + bf @ (proj_h @ lam), rtol=0, atol=1e-12 * abs(q).max())
+
+
+def forward_mode_array_operand(lib):
+    """``DeviceCsr @ a`` for a forward-mode AD array ``a`` (anything with ``val`` and ``jac``; the reference's
+    ``AdArray.__rmatmul__`` only takes scipy matrices, numerics/ad/forward_mode.py:565-592): value by the device SpMV,
+    Jacobian by the device product, result of the operand's own type."""
+    import porepy_amd as pa
+
+    class Ad:
+        def __init__(self, val, jac):
+            self.val, self.jac = val, jac
+
+    rng = np.random.default_rng(4)
+    ctx = pa.Context(0, lib)
+    M = sps.random(7, 5, density=0.5, random_state=1, format="csr")
+    J = sps.random(5, 9, density=0.4, random_state=2, format="csr")
+    v = rng.random(5)
+    Md = pa.DeviceCsr.from_scipy(M, ctx)
+    for jac in (J, pa.DeviceCsr.from_scipy(J, ctx)):
+        r = Md @ Ad(v, jac)
+        assert isinstance(r, Ad) and isinstance(r.jac, pa.DeviceCsr)
+        assert np.allclose(r.val, M @ v, rtol=0, atol=1e-15)
+        close(r.jac.to_scipy(), M @ J)

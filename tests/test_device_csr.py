@@ -11,6 +11,6 @@ def lib():
 
 
 @pytest.mark.parametrize("case", [cases.random_algebra, cases.input_checks, cases.discretization_to_system,
-                                  cases.merged_subdomains], ids=lambda f: f.__name__)
+                                  cases.merged_subdomains, cases.forward_mode_array_operand], ids=lambda f: f.__name__)
 def test_device_csr(lib, case):
     case(lib)

@@ -438,7 +438,8 @@ def test_sliver_grids_take_the_iterative_refinement_path(lib):
     P.sliver_refinement(lib)
 
 
-@pytest.mark.parametrize("case", ["random_algebra", "input_checks", "discretization_to_system", "merged_subdomains"])
+@pytest.mark.parametrize("case", ["random_algebra", "input_checks", "discretization_to_system", "merged_subdomains",
+                                  "forward_mode_array_operand"])
 def test_device_csr_algebra(lib, case):
     """SURVEY §8 row N4 on the gfx950 library: products, sums and block diagonals bit-identical to scipy's, the flow
     system assembled and solved without a discretization matrix leaving HBM (tests/_device_csr_cases.py)."""
