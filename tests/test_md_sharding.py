@@ -184,3 +184,25 @@ def test_jobs_of_one_discretization_object_go_to_its_batch_entry():
     assert stats["batch_calls"] == 2 and stats["jobs_in_batches"] == 26 and len(coupling.ran) == 12
     a, b = flat(mdg0), flat(mdg)
     assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_plan_properties_on_random_job_lists():
+    """Longest-processing-time-first: every job gets one owner, the loads add up, and no rank carries more than the
+    mean load plus the largest single job (the classical bound of the greedy assignment)."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.integers(min_value=1, max_value=5000), min_size=1, max_size=60), st.integers(min_value=1, max_value=9))
+    def check(cells, world):
+        grids = [Grid(2 + (i % 2), n, f"g{i}") for i, n in enumerate(cells)]
+        discr = {Mpfa("flow"): grids}
+        pl = S.plan(discr, world)
+        owners = [j.owner for j in pl.jobs]
+        assert len(owners) == len(grids) and all(0 <= o < world for o in owners)
+        total = sum(j.cost for j in pl.jobs)
+        assert abs(pl.load.sum() - total) <= 1e-9 * total
+        assert pl.load.max() <= total / world + max(j.cost for j in pl.jobs) + 1e-9
+        assert [j.owner for j in S.plan(discr, world).jobs] == owners
+
+    check()
