@@ -387,6 +387,74 @@ def cpu_baseline(ref_n_side: int, port_n_side: int):
     return port
 
 
+REFERENCE_HEADLINE_RUN = os.path.join(ROOT, "profiles", "r05_cpu_baseline_headline_grid_cached.json")
+
+
+def reference_source_digest():
+    """sha256 over the reference's source files of the hot path, as recorded by ``oracle/make_ref.py`` inside the
+    archive it builds (member ``SOURCE_DIGEST``; the live tree is hashed directly in the build container)."""
+    try:
+        from oracle import make_ref
+
+        return make_ref.source_digest()
+    except Exception:
+        return None
+
+
+def cached_cpu_headline():
+    """The reference's CPU path on the HEADLINE grid itself (1 971 054 tetrahedra, ``partition_arguments`` with 12
+    sub-problems): 6 minutes of host time, so the default run carries the RECORD of such a run (``--cpu-headline 12``
+    measures it live) -- valid for the reference sources whose digest it names."""
+    try:
+        with open(REFERENCE_HEADLINE_RUN) as fh:
+            rec = json.load(fh)
+    except Exception:
+        return None
+    out = dict(rec["cpu_baseline_headline_grid"])
+    dig = reference_source_digest()
+    out["cached"] = True
+    out["record"] = os.path.relpath(REFERENCE_HEADLINE_RUN, ROOT)
+    out["measured"] = rec.get("command")
+    out["reference_source_digest_of_the_record"] = rec.get("reference_source_digest")
+    out["reference_source_digest_here"] = dig
+    out["valid_for_this_reference"] = (dig == rec.get("reference_source_digest")) if dig else None
+    return out
+
+
+def whole_grid_check(pa, device_index: int, rtol: float, precond: str):
+    """Whole-grid parity datum at the headline size: the grid of the RECORDED reference run
+    (``oracle/ref_cpu_baseline.py 69 12``: make_problem(69) -- 1 971 054 tetrahedra, rng-perturbed nodes, log-normal
+    full-tensor K, unit source; ``profiles/r05_cpu_baseline_headline_grid_cached.json``) discretized, assembled and
+    solved on the device: nnz(flux) must EQUAL the reference's stored count (the structural stencil is the reference's
+    stored pattern on generic inputs), and the norm of the pressure field is compared with the reference's (whose own
+    Krylov solve stopped at a true residual of 1e-10)."""
+    with open(REFERENCE_HEADLINE_RUN) as fh:
+        rec = json.load(fh)["cpu_baseline_headline_grid"]
+    t0 = time.perf_counter()
+    g, K, bc, bv, src = make_problem(69)
+    ctx = pa.Context(device_index)
+    try:
+        ctx.set_grid(pa.grid_to_raw(g))
+        ctx.set_params(K.values, pa.bc_flags(bc), None, 1.0 / 3.0)
+        ctx.discretize(rebuild_topology=True)
+        ctx.assemble(bv, None, src)
+        x, info = ctx.solve("bicgstab", rtol=rtol, maxit=20000, raise_on_fail=False, precond=precond)
+        nnz_flux = int(ctx.matrix_info(pa._lib.MAT_FLUX)[2])
+        nnz_sys = int(ctx.matrix_info(pa._lib.MAT_SYSTEM)[2])
+    finally:
+        ctx.close()
+    pn = float(np.linalg.norm(x))
+    return {"grid": "make_problem(69): the grid of the recorded reference run (not the timed one: same lattice and "
+                    "stencil, nodes and K drawn from numpy's generator as oracle/ref_cpu_baseline.py does)",
+            "cells": int(g.num_cells), "flux_nnz_device": nnz_flux, "flux_nnz_reference": int(rec["flux_nnz"]),
+            "flux_nnz_equal": nnz_flux == int(rec["flux_nnz"]), "system_nnz_device": nnz_sys,
+            "p_norm_device": pn, "p_norm_reference": float(rec["check_norm"]),
+            "p_norm_rel_diff": abs(pn - float(rec["check_norm"])) / float(rec["check_norm"]),
+            "reference_solve": "scipy BiCGStab + Jacobi stopped at a true relative residual of 9.8e-11",
+            "device_iterations": int(info["iterations"]), "device_rel_residual": float(info["rel_residual"]),
+            "seconds_incl_host_grid": time.perf_counter() - t0}
+
+
 def source_hash() -> str:
     """Digest of the kernel sources: PMC files under profiles/ carry it, so counters are only quoted for the
     build they were collected with."""
@@ -525,6 +593,11 @@ def main():
                     help="also time the reference on the HEADLINE grid itself (configs[2] size) with "
                          "partition_arguments={'num_subproblems': K} (SURVEY 8(d)); minutes of host time: off by default, "
                          "the record of such a run is kept under profiles/")
+    ap.add_argument("--fixed-k", action="store_true",
+                    help="repeat the step on ONE permeability field (rounds 1-4) instead of a new field per step")
+    ap.add_argument("--no-cold", action="store_true", help="skip the secondary figure ms_per_step_cold")
+    ap.add_argument("--no-whole-grid-check", action="store_true",
+                    help="skip the whole-grid parity datum against the recorded reference run (profiling runs)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the secondary lines for BASELINE configs[1] and configs[3] (profiling runs)")
@@ -593,7 +666,28 @@ def main():
         d_x = torch.zeros(nloc, dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
 
+        # A NEW permeability field in every step: the log-normal factor is re-drawn per step from
+        # the global cell ids (same sparsity pattern, every VALUE moves), generated before the timed region and resident
+        # in HBM; the step forms K_i = K_aniso x factor_i on the device and hands it over device-to-device
+        # (pfv_mpfa_set_permeability).  Whatever the library keeps between steps is therefore kept across MOVING values.
+        n_fields = 1 if args.fixed_k else min(64, 6 + args.warmup + args.steps + 1)
+        base_scale = np.exp(0.5 * _hash_normal(lp.cell_gid, 7))
+        d_aniso = torch.from_numpy(np.ascontiguousarray(Kvals / base_scale[None, None, :])).to(dev)   # (3, 3, nloc)
+        fields = [base_scale] + [np.exp(0.5 * _hash_normal(lp.cell_gid, 1000 + 2 * i)) for i in range(1, n_fields)]
+        d_fac = torch.from_numpy(np.ascontiguousarray(np.stack(fields))).to(dev)                      # (n_fields, nloc)
+        d_K = torch.empty_like(d_aniso)
+        del fields
+        step_no = [0]
+        torch.cuda.synchronize()
+
+        def set_field(i):
+            torch.mul(d_aniso, d_fac[i % n_fields][None, None, :], out=d_K)
+            torch.cuda.current_stream().synchronize()   # (torch's stream -> the handle's stream)
+            ctx.set_permeability_device(d_K.data_ptr())
+
         def step():
+            step_no[0] += 1
+            set_field(step_no[0])
             ctx.discretize(rebuild_topology=True)
             ctx.assemble_device(d_bv.data_ptr(), 0, d_src.data_ptr())
             info = ctx.solve_device(d_x.data_ptr(), "bicgstab", rtol=args.rtol, maxit=20000, raise_on_fail=False,
@@ -612,8 +706,17 @@ def main():
         torch.cuda.synchronize()
         drv = os.environ.get("PFV_SHARDED_DRIVER", "library")
 
+        # as above: a new log-normal factor per step, a function of the GLOBAL cell ids (one global field on all ranks)
+        n_fields = 1 if args.fixed_k else min(32, 6 + args.warmup + args.steps + 1)
+        base_scale = np.exp(0.5 * _hash_normal(lp.cell_gid, 7))
+        k_aniso = Kvals / base_scale[None, None, :]
+        k_fields = [Kvals] + [np.ascontiguousarray(k_aniso * np.exp(0.5 * _hash_normal(lp.cell_gid, 1000 + 2 * i))[None, None, :])
+                              for i in range(1, n_fields)]
+        step_no = [0]
+
         def step():
-            sh.discretize(Kvals, flags, None, eta, skip_vector_source=False, rebuild_topology=True)
+            step_no[0] += 1
+            sh.discretize(k_fields[step_no[0] % n_fields], flags, None, eta, skip_vector_source=False, rebuild_topology=True)
             sh.assemble(d_bv, d_src)
             return sh.solve("bicgstab", rtol=args.rtol, maxit=20000, precond=args.precond, driver=drv)
 
@@ -655,6 +758,43 @@ def main():
         elapsed = float(t.item())
     st = ctx.stats()
     ms_per_step = 1e3 * elapsed / args.steps
+    # ---- the same step with NOTHING kept between steps (aggregate maps, SpMV windows, filter layout, Galerkin sizes
+    # all rebuilt): the cold figure beside the headline
+    cold = None
+    if not args.no_cold:
+        off = {"PFV_AMG_REUSE_REBUILT": "0", "PFV_WIN_REUSE": "0", "PFV_AMG_FILTER_LAYOUT_REUSE": "0", "PFV_AMG_SIZES_REUSE": "0"}
+        saved = {k: os.environ.get(k) for k in off}
+        os.environ.update(off)
+        try:
+            step()
+            barrier()
+            tc0 = time.perf_counter()
+            ncold = max(2, min(args.steps, 5))
+            for _ in range(ncold):
+                xc, infoc = step()
+            ctx.sync()
+            barrier()
+            tcold = time.perf_counter() - tc0
+            if dist is not None:
+                tt = torch.tensor([tcold], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tcold = float(tt.item())
+            stc = ctx.stats()
+            cold = {"ms_per_step_cold": 1e3 * tcold / ncold, "steps": ncold,
+                    "iterations": int(infoc["iterations"]) if isinstance(infoc, dict) else None,
+                    "amg_setup_ms": stc["amg_setup_ms"], "kept": {"amg_aggregate_maps": int(stc.get("amg_maps_reused", 0)),
+                                                                   "spmv_windows": int(stc.get("win_reused", 0)),
+                                                                   "amg_filter_layout": int(stc.get("amg_filter_layout", 0))},
+                    "switches": off}
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        x, info = step()   # (back to the default step: the diagnostics below look at its state)
+        ctx.sync()
+        st = ctx.stats()
     ncells_total = nc
     if dist is not None:
         tcount = torch.tensor([nc], dtype=torch.int64, device="cuda")
@@ -821,10 +961,18 @@ def main():
         except Exception as e:  # diagnostics only
             field = {"error": repr(e)}
     cpu_headline = None
+    whole_grid = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_n_side, args.cpu_port_n_side)
     if rank == 0 and world == 1 and args.cpu_headline > 0:
         cpu_headline = cpu_baseline_reference(args.n_side, timeout_s=3000.0, num_sub=args.cpu_headline, solve_cap_s=600.0)
+    elif rank == 0 and world == 1 and args.n_side == 69:
+        cpu_headline = cached_cpu_headline()
+    if rank == 0 and world == 1 and not args.force_sharded and args.n_side == 69 and not args.no_whole_grid_check:
+        try:
+            whole_grid = whole_grid_check(pa, local_rank, args.rtol, args.precond)
+        except Exception as e:  # diagnostics only
+            whole_grid = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.force_sharded and args.n_side == 69 and not args.no_extra_configs:
         try:
             opapi = bench_operator_api(pa, lp, Kvals, flags, bv, src, eta, local_rank)
@@ -876,18 +1024,20 @@ def main():
                                          "amg_filter_layout": int(st.get("amg_filter_layout", 0)),
                                          "value_dependent_note": "amg_filter_layout 1 = the strength filter of the AMG setup wrote "
                                                                  "into the row layout of the previous step's filtering instead of "
-                                                                 "counting + scanning first (-0.7 ms): that layout depends on the "
-                                                                 "VALUES; it fits because the bench repeats the step on the same "
-                                                                 "coefficients (offered only after a setup that reproduced the "
-                                                                 "layout before it; with coefficients that move it is not tried: "
-                                                                 "PFV_AMG_FILTER_LAYOUT_REUSE=0 gives that step).  The filtered "
-                                                                 "windows and the sizes of the Galerkin products are kept on the "
-                                                                 "same terms (checksum of the filtered index arrays)",
+                                                                 "counting + scanning first: only offered after a setup that "
+                                                                 "reproduced the layout before it, so with a field that moves "
+                                                                 "every step (the default) it stays 0; the filtered windows and the "
+                                                                 "Galerkin sizes are kept only on an equal digest of the FILTERED "
+                                                                 "index arrays, which moving values do not reproduce either",
                                          "note": "every step rebuilds the sub-cell topology, all CSR patterns, all values, the "
-                                                 "strength filter, the Galerkin products and the solve; the aggregate maps of the "
-                                                 "AMG levels and the SpMV windows of A -- functions of A's pattern -- are kept when "
-                                                 "the symbolic phase proves the new pattern equal (sizes + 64-bit checksum of the "
-                                                 "index arrays); PFV_AMG_REUSE_REBUILT=0 PFV_WIN_REUSE=0 rebuilds them too"},
+                                                 "strength filter, the Galerkin products and the solve, on a permeability field "
+                                                 "that changes from step to step.  Kept when the symbolic phase proves A's new "
+                                                 "pattern equal (sizes + 64-bit digest of the index arrays): the SpMV windows of A "
+                                                 "(a function of the pattern alone) and the pairwise aggregate maps of the AMG "
+                                                 "levels -- the latter follow the strength of connection of the VALUES they were "
+                                                 "built from, i.e. the cycle coarsens along the previous step's field (what a "
+                                                 "nonlinear iteration does); what that costs or saves shows against "
+                                                 "ms_per_step_cold, where nothing is kept"},
                        "sparsity_pattern": "structural stencil: a superset of the reference's stored pattern (bit-identical on "
                                            "generic anisotropic inputs; where the reference's sparse products drop exact zeros, "
                                            "what is stored outside its pattern is < 1e-12 of the row maximum)",
@@ -907,6 +1057,13 @@ def main():
                        "AMG: per level and visit 2 point-to-point halo exchanges, one all-gather at the gathered level"},
             "roofline": roofline, "roofline_kernels": kernels[1:], "kernel_ms_per_step": per_step_ms,
             "hbm_triad_measured_GBs": triad_gbs, "hbm_read_stream_measured_GBs": read_gbs,
+            "ms_per_step_cold": (cold or {}).get("ms_per_step_cold"), "cold_step": cold,
+            "permeability_per_step": ("one field repeated (--fixed-k)" if args.fixed_k else
+                                      f"a new log-normal field every step ({n_fields} fields resident in HBM, cycled)"),
+            "launches_per_iteration": (st.get("solve_launches", 0) / max(its, 1)) if its else None,
+            "solve_launches": {"krylov_loop": int(st.get("solve_launches", 0)), "amg_setup": int(st.get("amg_setup_launches", 0)),
+                               "note": "this library's kernel dispatches of the last timed solve (rocPRIM primitives, memsets and copies not counted)"},
+            "whole_grid_check": whole_grid,
             "assembly": assembly, "operator_api": opapi, "cpu_baseline": cpu, "cpu_baseline_headline_grid": cpu_headline,
             "config_c2": c2, "config_c4": c4,
         }

@@ -121,6 +121,10 @@ typedef struct {
   int64_t amg_filter_layout;      /* last AMG setup's strength filter: 0 counted and scanned the kept entries, 1 wrote into
                                      the row layout of the previous filtering of the same pattern (every row kept as many
                                      entries as its slot held), 2 tried that, found a row that did not, and ran again */
+  int64_t solve_launches;         /* kernel dispatches of the last pfv_solve's Krylov loop, preconditioner applications
+                                     included, its setup excluded (this library's own kernels; rocPRIM primitives, memsets
+                                     and copies are not counted) */
+  int64_t amg_setup_launches;     /* ... of the last preconditioner setup */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);
@@ -147,6 +151,13 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn,
 pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t* bc_flags,
                                const double* robin_weight, double eta,
                                const double* eta_subface);
+
+/* New permeability values only (same shape and order as above), everything else of pfv_mpfa_set_params kept: what
+ * the step of a nonlinear / time-dependent model changes between two Mpfa.discretize calls (the reference reads
+ * data[PARAMETERS][kw]["second_order_tensor"] afresh in every call, numerics/fv/mpfa.py:121-122).  perm_33n is host
+ * memory, or device memory after pfv_set_vectors_on_device(h, 1) (copied device-to-device: the coefficient field of
+ * a model that evaluates K on the GPU never crosses PCIe). */
+pfv_status pfv_mpfa_set_permeability(pfv_ctx* h, const double* perm_33n);
 
 /* Residual and Jacobian of the flow equation with a pressure-dependent permeability, on the device
  * (csrc/ad_flux.inc; the reference: AdTpfaFlux.diffusive_flux with an Mpfa base discretization,

@@ -40,6 +40,39 @@ for _m in SUITE:
     EXTRA["reference_tests/" + os.path.basename(_m) + ".pyc"] = "/root/reference/tests/" + _m + ".py"
 
 
+# the reference's source files of the hot path: their digest keys records of reference RUNS that are
+# too long to repeat in every bench invocation (bench.py: cached_cpu_headline)
+PATH_FILES = ["numerics/fv/mpfa.py", "numerics/fv/_fvutils.py", "numerics/fv/fv_elliptic.py", "numerics/fv/mpsa.py",
+              "numerics/fv/tpfa.py", "numerics/fv/biot.py", "numerics/linalg/matrix_operations.py",
+              "numerics/discretization.py"]
+
+
+def _live_digest() -> str | None:
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in PATH_FILES:
+        p = os.path.join(REF_SRC, "porepy", rel)
+        if not os.path.exists(p):
+            return None
+        h.update(rel.encode())
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def source_digest(archive: str = ARCHIVE) -> str | None:
+    """Digest of the reference's hot-path sources: of the live tree where it exists, else the one recorded in the
+    archive when it was built."""
+    d = _live_digest()
+    if d is not None:
+        return d
+    try:
+        with zipfile.ZipFile(archive) as z:
+            return z.read("SOURCE_DIGEST").decode().strip()
+    except (OSError, KeyError, zipfile.BadZipFile):
+        return None
+
+
 def build(force: bool = False) -> str | None:
     pkg = os.path.join(REF_SRC, "porepy")
     if not os.path.isdir(pkg):
@@ -79,6 +112,7 @@ def build(force: bool = False) -> str | None:
         z.write(init_pyc, "reference_tests/__init__.pyc")
         # the interpreter that wrote the members: an archive is only usable by the same bytecode magic
         z.writestr("PYC_MAGIC", importlib.util.MAGIC_NUMBER.hex())
+        z.writestr("SOURCE_DIGEST", _live_digest() or "")
     os.replace(tmp, ARCHIVE)
     return ARCHIVE
 

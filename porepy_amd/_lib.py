@@ -43,6 +43,7 @@ EXPORTS = [
     "pfv_rccl_unique_id", "pfv_rccl_comm_create", "pfv_rccl_set_halo_plan", "pfv_rccl_hooks", "pfv_rccl_stats",
     "pfv_rccl_last_error", "pfv_rccl_comm_destroy", "pfv_mpfa_ad_flux_system", "pfv_host_alloc", "pfv_host_free",
     "pfv_mpsa_set_subface_eta", "pfv_mpsa_set_reconstruction_eta", "pfv_get_stats_n", "pfv_set_block_preconditioner",
+    "pfv_mpfa_set_permeability",
 ]
 
 
@@ -61,7 +62,8 @@ class Stats(C.Structure):
                 ("amg_coarsest_rows", C.c_int64), ("discretize_ms", C.c_double), ("solve_renumbered", C.c_int64),
                 ("node_flops", C.c_double), ("node_table_doubles", C.c_int64),
                 ("amg_maps_reused", C.c_int64), ("amg_level0_nnz", C.c_int64), ("amg_filter_theta", C.c_double),
-                ("win_reused", C.c_int64), ("amg_filter_layout", C.c_int64)]
+                ("win_reused", C.c_int64), ("amg_filter_layout", C.c_int64),
+                ("solve_launches", C.c_int64), ("amg_setup_launches", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -112,6 +114,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_set_grid.restype = C.c_int
     lib.pfv_mpfa_set_params.argtypes = [_h, _dp, _up, _dp, C.c_double, _dp]
     lib.pfv_mpfa_set_params.restype = C.c_int
+    lib.pfv_mpfa_set_permeability.argtypes = [_h, _dp]
+    lib.pfv_mpfa_set_permeability.restype = C.c_int
     lib.pfv_mpfa_discretize.argtypes = [_h, C.c_uint32]
     lib.pfv_mpfa_discretize.restype = C.c_int
     lib.pfv_mpfa_discretize_faces.argtypes = [_h, C.c_uint32, C.c_int64, _ip, C.c_int]
@@ -574,6 +578,21 @@ class Context:
             raise ValueError("size of eta must either be 1 or number of subfaces")
         self._check(self.lib.pfv_mpfa_set_params(self._h, _ptr(perm, _dp), _ptr(flags, _up),
                                                  _ptr(rw, _dp), float(eta), _ptr(es, _dp)))
+
+    def set_permeability(self, perm):
+        """New permeability values (3, 3, Nc), everything else of ``set_params`` kept."""
+        perm = _f64(perm)
+        if perm.shape != (3, 3, self.nc):
+            raise ValueError(f"permeability must have shape (3, 3, {self.nc})")
+        self._check(self.lib.pfv_mpfa_set_permeability(self._h, _ptr(perm, _dp)))
+
+    def set_permeability_device(self, perm_ptr: int):
+        """``set_permeability`` from a device buffer of 9 Nc doubles ((3, 3, Nc) C-order), copied device-to-device."""
+        self._dev(True)
+        try:
+            self._check(self.lib.pfv_mpfa_set_permeability(self._h, C.cast(perm_ptr, _dp)))
+        finally:
+            self._dev(False)
 
     def set_subface_bc(self, bc_flags_sub, robin_weight_sub=None):
         """Boundary conditions per sub-face (face_nodes CSC order, sorted indices); None switches back to

@@ -107,13 +107,20 @@ def assemble_on_device(equation_system, context: "_lib.Context", state=None, equ
     base = device_ad_base(equation_system, context, state)
     vals, jacs = [], []
     leaves = device_matrix_leaves(context) if device_leaves else contextlib.nullcontext()
+    # rows of every assembled equation, as EquationSystem.assemble leaves them (equation_system.py:1654-1693): the
+    # block preconditioner (HipLinearSolver) and the reference's diagnostics read them
+    indices, start = {}, 0
     try:
         with leaves:
             for name in names:
                 ad = evaluate_on_device(equation_system.equations[name], equation_system, context, ad_base=base)
+                rows = int(np.asarray(ad.val).size)
+                indices[name] = np.arange(rows) + start
+                start += rows
                 if ad.val.size:
                     vals.append(ad.val)
                     jacs.append(ad.jac)
+        equation_system.assembled_equation_indices = indices
     finally:
         equation_system._ad_parser.clear_cache()
     J = jacs[0] if len(jacs) == 1 else vstack(jacs, context)

@@ -39,6 +39,13 @@
 // to the flat address space and every LDS access becomes a (slow, vmcnt-coupled) flat_load/store
 #define PFV_FN __host__ __device__ __attribute__((always_inline)) inline
 #define PFV_LAMBDA [=] __device__
+// (the kernel name is parenthesised here: HIP_KERNEL_NAME(k<a, b>) has lost its protecting parentheses by the time the
+// argument is substituted)
+#define PFV_LAUNCH(kernel, ...)                  \
+  do {                                           \
+    ++::pfv::launch_counter();                   \
+    hipLaunchKernelGGL((kernel), __VA_ARGS__);   \
+  } while (0)
 #endif
 // lane-strided loop of the wavefront (or lane group) that owns work item `w`
 #define PFV_LANES(i, n) for (int i = w.lane; i < (int)(n); i += w.width)
@@ -51,6 +58,12 @@ struct Error : std::runtime_error {
 };
 
 constexpr int kWave = 64;
+
+// kernel dispatches issued by this library (every launch site goes through PFV_LAUNCH): pfv_stats.solve_launches
+inline long long& launch_counter() {
+  static long long c = 0;
+  return c;
+}
 
 #ifndef PFV_EMULATE
 #define PFV_HIP_CHECK(expr)                                                              \
@@ -510,7 +523,7 @@ inline void parallel_for(stream_t s, int64_t n, F f) {
 #else
   int64_t blocks = (n + 255) / 256;
   if (blocks > 16384) blocks = 16384;  // grid-stride beyond 64 blocks per CU
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_parallel_for<F>), dim3((unsigned)blocks), dim3(256), 0, s, n, f);
+  PFV_LAUNCH(HIP_KERNEL_NAME(k_parallel_for<F>), dim3((unsigned)blocks), dim3(256), 0, s, n, f);
   PFV_HIP_CHECK(hipGetLastError());
 #endif
 }
@@ -538,7 +551,7 @@ inline void wave_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
     PFV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_for<G, F>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wave_for<G, F>), dim3((unsigned)blocks), dim3(64), block_lds, s, n,
+  PFV_LAUNCH(HIP_KERNEL_NAME(k_wave_for<G, F>), dim3((unsigned)blocks), dim3(64), block_lds, s, n,
                      lds_bytes, f);
   PFV_HIP_CHECK(hipGetLastError());
 #endif
@@ -559,7 +572,7 @@ inline void wave_for_occ(stream_t s, int64_t n, size_t lds_bytes, F f) {
     PFV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_for_occ<G, W, F>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wave_for_occ<G, W, F>), dim3((unsigned)blocks), dim3(64), block_lds, s, n,
+  PFV_LAUNCH(HIP_KERNEL_NAME(k_wave_for_occ<G, W, F>), dim3((unsigned)blocks), dim3(64), block_lds, s, n,
                      lds_bytes, f);
   PFV_HIP_CHECK(hipGetLastError());
 }
@@ -592,7 +605,7 @@ inline void wave_for_xcd(stream_t s, int64_t n, size_t lds_bytes, F f) {
     PFV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wave_for_xcd<64, F>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wave_for_xcd<64, F>), dim3((unsigned)blocks), dim3(64), lds_bytes, s, n,
+  PFV_LAUNCH(HIP_KERNEL_NAME(k_wave_for_xcd<64, F>), dim3((unsigned)blocks), dim3(64), lds_bytes, s, n,
                      lds_bytes, f);
   PFV_HIP_CHECK(hipGetLastError());
 #endif
@@ -646,7 +659,7 @@ inline void block_for_global(stream_t s, int64_t n, size_t bytes, Buf<char>& scr
 #else
   const int64_t blocks = n < 256 ? n : 256;
   char* buf = scratch.ensure((size_t)blocks * bytes);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_for_global<T, F>), dim3((unsigned)blocks), dim3(T), 256, s, n, bytes, buf, f);
+  PFV_LAUNCH(HIP_KERNEL_NAME(k_block_for_global<T, F>), dim3((unsigned)blocks), dim3(T), 256, s, n, bytes, buf, f);
   PFV_HIP_CHECK(hipGetLastError());
 #endif
 }
@@ -670,7 +683,7 @@ inline void block_for(stream_t s, int64_t n, size_t lds_bytes, F f) {
     PFV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_for<T, F>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)total));
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_block_for<T, F>), dim3((unsigned)blocks), dim3(T), total, s, n, lds_bytes, f);
+  PFV_LAUNCH(HIP_KERNEL_NAME(k_block_for<T, F>), dim3((unsigned)blocks), dim3(T), total, s, n, lds_bytes, f);
   PFV_HIP_CHECK(hipGetLastError());
 #endif
 }

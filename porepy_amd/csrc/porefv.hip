@@ -313,6 +313,17 @@ pfv_status pfv_mpfa_set_params(pfv_ctx* h, const double* perm_33n, const uint8_t
   });
 }
 
+pfv_status pfv_mpfa_set_permeability(pfv_ctx* h, const double* perm_33n) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_params, "pfv_mpfa_set_params first");
+    require(perm_33n != nullptr, "null parameter array");
+    h->perm.ensure(9 * (size_t)h->nc);
+    vec_in(h, h->perm.p, perm_33n, 9 * (size_t)h->nc);
+    h->have_numeric = h->have_system = false;
+    h->win_sys_prebuilt = h->win_rows_prebuilt = false;
+  });
+}
+
 pfv_status pfv_mpfa_set_subface_bc(pfv_ctx* h, const uint8_t* bc_flags_sub, const double* robin_weight_sub) {
   return guarded(h, [&] {
     require(h->have_grid && h->have_params, "pfv_mpfa_set_params first");
@@ -1572,6 +1583,7 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
     }
     pfv::Precond M;
     const pfv::Precond* Mp = nullptr;
+    const long long launches_before_setup = pfv::launch_counter();
     if (h->precond == PFV_PRECOND_AMG) {
       if (!h->amg) h->amg = std::make_unique<pfv::Amg>();
       if (!h->amg->valid || h->amg_for_val != sys.val) {
@@ -1600,9 +1612,12 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
       M.diag = sys.diag;
       Mp = &M;
     }
+    const long long launches_before_loop = pfv::launch_counter();
+    h->stats.amg_setup_launches = (int64_t)(launches_before_loop - launches_before_setup);
     res = method == PFV_SOLVE_GMRES
               ? pfv::gmres_solve(*h, sys, rtol, maxit, restart, dxs, x0 == nullptr, Mp)
               : pfv::krylov_solve(*h, sys, method, rtol, maxit, dxs, x0 == nullptr, Mp);
+    h->stats.solve_launches = (int64_t)(pfv::launch_counter() - launches_before_loop);
     if (permuted) pfv::permute_vector(*h, (int64_t)n, h->active_bs, dxs, dx, false);
     h->stats.solve_ms = tm.stop(s);
     if (h->vectors_on_device) pfv::be_d2d(x, dx, n * sizeof(double), s); else be_d2h(x, dx, n * sizeof(double), s);
@@ -1785,7 +1800,7 @@ pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms) {
           a2[i].y = b2[i].y + 0.5 * c2[i].y;
         }
 #else
-        hipLaunchKernelGGL(pfv::k_triad, dim3(256 * 16), dim3(256), 0, s, (int64_t)(n / 2), a2, b2, c2);
+        PFV_LAUNCH(pfv::k_triad, dim3(256 * 16), dim3(256), 0, s, (int64_t)(n / 2), a2, b2, c2);
         PFV_HIP_CHECK(hipGetLastError());
 #endif
       };
@@ -1802,7 +1817,7 @@ pfv_status pfv_time_kernel(pfv_ctx* h, int kernel, int reps, double* avg_ms) {
       double* a = buf.ensure(n + 8);
       pfv::be_memset(a, 0, (n + 8) * sizeof(double), s);
       auto rd = [&] {
-        hipLaunchKernelGGL(pfv::k_read_stream, dim3(256 * 16), dim3(256), 0, s, (int64_t)(n / 2),
+        PFV_LAUNCH(pfv::k_read_stream, dim3(256 * 16), dim3(256), 0, s, (int64_t)(n / 2),
                            reinterpret_cast<const pfv::D2*>(a), a + n);
         PFV_HIP_CHECK(hipGetLastError());
       };

@@ -26,6 +26,24 @@ import numpy as np
 from . import _lib
 
 
+def _content_key(m):
+    """What a remembered upload of the host matrix ``m`` is valid for: shape, nnz and a digest of its VALUES (all of
+    them up to 2 M entries, a strided sample of 64 k beyond), so that a matrix rescaled in place (``m.data[:] = ...``,
+    ``m *= s``) is uploaded again instead of being served from the stale device copy."""
+    data = getattr(m, "data", None)
+    if not isinstance(data, np.ndarray) or data.ndim != 1:
+        return (getattr(m, "shape", None), getattr(m, "nnz", None), None)
+    n = data.size
+    sample = data if n <= (1 << 21) else data[:: max(1, n >> 16)]
+    w = np.arange(1, sample.size + 1, dtype=np.float64)
+    return (m.shape, m.nnz, float(sample.sum()), float(np.dot(sample, w % 977.0)))
+
+
+def clear_upload_cache() -> None:
+    """Forget every remembered upload of a host matrix (and release the HBM of the device copies nobody else holds)."""
+    _UPLOADS.clear()
+
+
 class DeviceCsr:
     """One CSR matrix (FP64 values, int32 indices) resident on the device of ``context``."""
 
@@ -78,11 +96,12 @@ class DeviceCsr:
             # an operand that lives on the host (divergence, projection, eager discretization matrix): uploaded once,
             # remembered while the host object is alive and unchanged in size
             hit = _UPLOADS.get(id(m))
-            if hit is not None and hit[0]() is m and hit[1].ctx is context and hit[1]._c and hit[2] == (m.shape, m.nnz):
+            key = _content_key(m)
+            if hit is not None and hit[0]() is m and hit[1].ctx is context and hit[1]._c and hit[2] == key:
                 return hit[1]
             d = cls.from_scipy(m, context)
             try:
-                _UPLOADS[id(m)] = (weakref.ref(m, lambda _r, k=id(m): _UPLOADS.pop(k, None)), d, (m.shape, m.nnz))
+                _UPLOADS[id(m)] = (weakref.ref(m, lambda _r, k=id(m): _UPLOADS.pop(k, None)), d, key)
             except TypeError:
                 pass
             return d

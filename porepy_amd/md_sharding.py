@@ -129,12 +129,27 @@ def _matrix_slots(pp, mdg, job: Job):
     return [mdg.subdomain_data(job.grid)]
 
 
+def _digest(v):
+    """Cheap content digest of a stored matrix / array: a discretization that updates a stored matrix IN PLACE (same
+    object, new values) is then still seen as a change by the job that did it."""
+    try:
+        if sps.issparse(v):
+            d = np.asarray(v.data)
+            return (v.shape, int(v.nnz), float(d.sum()), float(np.abs(d).sum()))
+        if isinstance(v, np.ndarray):
+            return (v.shape, float(np.sum(v)), float(np.abs(v).sum()))
+    except Exception:  # noqa: BLE001 - a value without a cheap digest is compared by identity only
+        pass
+    return None
+
+
 def _snapshot(pp, slots):
     snap = {}
     for s, d in enumerate(slots):
         for kw, md in d.get(pp.DISCRETIZATION_MATRICES, {}).items():
             for name, v in md.items():
-                snap[(s, kw, name)] = v  # (the object itself: an id could be recycled once the job overwrites it)
+                # (the object itself: an id could be recycled once the job overwrites it; the digest catches in-place updates)
+                snap[(s, kw, name)] = (v, _digest(v))
     return snap
 
 
@@ -172,6 +187,7 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
             world, rank = 1, 0
     pl = plan(discretizations, world, cost, is_interface=lambda g: isinstance(g, pp.MortarGrid))
     mine: dict = {}
+    mine_objects: dict = {}  # the same entries with the objects as stored here (device-resident proxies stay what they are)
     own = [i for i, job in enumerate(pl.jobs) if job.owner == rank]
     slots_of = {i: _matrix_slots(pp, mdg, pl.jobs[i]) for i in own}
     before_of = {i: _snapshot(pp, slots_of[i]) for i in own}
@@ -191,13 +207,16 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
     for i in own:
         if i not in done:
             _run(pp, mdg, pl.jobs[i], slots_of[i])
-        out = []
+        out, kept = [], []
         for s, d in enumerate(slots_of[i]):
             for kw, md in d.get(pp.DISCRETIZATION_MATRICES, {}).items():
                 for name, v in md.items():
-                    if before_of[i].get((s, kw, name), _ABSENT) is not v:
+                    was = before_of[i].get((s, kw, name), _ABSENT)
+                    if was is _ABSENT or was[0] is not v or was[1] != _digest(v):
                         out.append((s, kw, name, _host_value(v)))
+                        kept.append((s, kw, name, v))
         mine[i] = out
+        mine_objects[i] = kept
     sent = 0
     if world > 1:
         if exchange is None:
@@ -207,13 +226,18 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
                 got = [None] * world
                 dist.all_gather_object(got, payload, group=group)
                 return got
+        # Every rank applies ALL results -- its own too -- in ascending job index, i.e. in the order of the reference's
+        # loop (ad_utils.py:288-308): where two jobs write the same (slot, keyword, name) (an interface discretization
+        # and a subdomain discretization storing into the primary grid's dictionary), the last writer of the serial
+        # loop wins on every rank, whoever ran it.
+        results: dict = {}
         for r, theirs in enumerate(exchange(mine)):
-            if r == rank:
-                continue
-            for i in sorted(theirs):
-                slots = _matrix_slots(pp, mdg, pl.jobs[i])
-                for (s, kw, name, v) in theirs[i]:
-                    slots[s].setdefault(pp.DISCRETIZATION_MATRICES, {}).setdefault(kw, {})[name] = v
+            for i, payload in (mine_objects if r == rank else theirs).items():
+                results[i] = payload
+        for i in sorted(results):
+            slots = slots_of[i] if i in slots_of else _matrix_slots(pp, mdg, pl.jobs[i])
+            for (s, kw, name, v) in results[i]:
+                slots[s].setdefault(pp.DISCRETIZATION_MATRICES, {}).setdefault(kw, {})[name] = v
         for out in mine.values():
             for (_, _, _, v) in out:
                 if sps.issparse(v):

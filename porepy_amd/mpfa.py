@@ -294,6 +294,8 @@ class Mpfa:
         for k in keys:
             self._contexts.pop(k, None)
             self._fingerprints.pop(k, None)
+            self._plane.pop(k, None)      # (a later grid object may reuse the id: no stale basis / merge map)
+            self._periodic.pop(k, None)
 
     def _upload_grid(self, ctx, sd):
         raw = grid_to_raw(sd)
@@ -410,9 +412,11 @@ class Mpfa:
         md = data[DISCRETIZATION_MATRICES][self.keyword]
         div = sd.cell_faces.T.tocsr()
         q = md["bound_flux"] @ np.asarray(pd["bc_values"], dtype=float)
-        vs = self._vector_source(sd, pd)
+        # the merged / split-off matrices are in the CALLER's coordinates (a plane of a union carries the lift to the
+        # ambient space in its vector-source columns already): the vector source is taken as given, not projected
+        vs = pd.get("vector_source", None)
         if vs is not None:
-            q = q + md["vector_source"] @ vs
+            q = q + md["vector_source"] @ np.asarray(vs, dtype=float)
         b = -(div @ q)
         if source is not None:
             b = b + np.asarray(source, dtype=float)
@@ -708,6 +712,7 @@ class Mpfa:
                 pd["active_cells"] = np.arange(sd.num_cells)
                 pd["active_faces"] = np.arange(sd.num_faces)
                 self.invalidate(sd)  # (no handle of its own holds this grid's discretization:
+                self._plane[id(sd)] = T  # the basis this member was discretized in
                 A_g = sps.csr_matrix(A_union[c0:c1][:, c0:c1])  # assemble_matrix_rhs goes the way of a grid in pieces)
                 A_g.sort_indices()
                 self._split[id(sd)] = (sd, A_g)

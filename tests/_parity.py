@@ -1108,7 +1108,7 @@ def patch_targets(raw: dict, n_random: int = 6, seed: int = 3):
     return cells
 
 
-def reference_on_patches(patches, product: bool):
+def reference_on_patches(patches, product: bool, keys=None):
     """The REFERENCE ITSELF (pp.Mpfa, python inverter) on patches [(lraw, K, lbc, eta)], in one subprocess
     (tests/_reference_patch_script.py; the live tree in the build container, the byte-compiled archive on the GPU box).
     Returns a list of {key: csr} or None where no reference is importable."""
@@ -1118,13 +1118,16 @@ def reference_on_patches(patches, product: bool):
 
     import oracle
 
+    keys = ALL_KEYS if keys is None else keys
     env = oracle.ref_env(prefer_archive=product)
     if env is None:
         return None
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory(prefix="pfv_patches_") as d:
         for i, (lraw, K, lbc, eta) in enumerate(patches):
-            np.savez(os.path.join(d, f"patch_{i:03d}.npz"), K=K, is_dir=lbc["is_dir"], is_neu=lbc["is_neu"], eta=eta,
+            # (mechanics: the tensor is the (9, 9, Nc) stiffness -- the script then runs pp.Mpsa)
+            tensor = {"stiffness": K} if keys is not ALL_KEYS else {"K": K}
+            np.savez(os.path.join(d, f"patch_{i:03d}.npz"), is_dir=lbc["is_dir"], is_neu=lbc["is_neu"], eta=eta, **tensor,
                      **{k: v for k, v in lraw.items() if isinstance(v, (np.ndarray, int, str))})
         r = subprocess.run([sys.executable, os.path.join(root, "tests", "_reference_patch_script.py"), d], env=env,
                            cwd="/tmp", capture_output=True, text=True, timeout=1500)
@@ -1133,7 +1136,7 @@ def reference_on_patches(patches, product: bool):
         for i in range(len(patches)):
             z = np.load(os.path.join(d, f"ref_{i:03d}.npz"))
             out.append({k: sps_csr((z[k + "_data"], z[k + "_indices"], z[k + "_indptr"]), shape=tuple(z[k + "_shape"]))
-                        for k in ALL_KEYS})
+                        for k in keys})
     return out
 
 
@@ -1602,7 +1605,7 @@ def amg_robustness_sweep(lib, scale: float = 1.0):
     return out
 
 
-def mpsa_patch_parity_all_matrices(lib, n_side: int = 44, n_random: int = 4):
+def mpsa_patch_parity_all_matrices(lib, n_side: int = 44, n_random: int = 4, reference: bool = False):
     """BASELINE configs[3] (MPSA elasticity, rollers + top traction, perturbed tetrahedra) at full size: all FOUR
     device matrices (stress, bound_stress, bound_displacement_cell, bound_displacement_face) and the system matrix
     on patches (8 box corners -- where roller, traction and free faces meet --, 6 side centres, random cells) against
@@ -1633,6 +1636,7 @@ def mpsa_patch_parity_all_matrices(lib, n_side: int = 44, n_random: int = 4):
     cutter = PatchCutter(raw)
     ex = lambda idx: (nd * np.asarray(idx)[:, None] + np.arange(nd)[None, :]).ravel()  # noqa: E731
     worst, checked = {}, 0
+    ref_inputs, ref_rows = [], []
     targets = patch_targets(raw, n_random, seed=6)
     for c0 in targets:
         inner = cutter.cells_around(c0)
@@ -1648,16 +1652,42 @@ def mpsa_patch_parity_all_matrices(lib, n_side: int = 44, n_random: int = 4):
         cmap[ex(cell_gid)] = np.arange(nd * cell_gid.size)
         fmap = np.full(nd * nf, -1)
         fmap[ex(face_gid)] = np.arange(nd * face_gid.size)
+        if reference:
+            ref_inputs.append((lraw, np.ascontiguousarray(C.values[:, :, cell_gid]), {"is_dir": ldir, "is_neu": lneu}, eta))
+            ref_rows.append({"rows": ex(lfaces)})
         for k in MPSA_KEYS:
             m = cmap if k in ("stress", "bound_displacement_cell") else fmap
             G = ctx.matrix_rows(MPSA_WHICH[k], ex(gfaces)).tocoo()
             assert np.all(m[G.col] >= 0), (k, c0)
             Gl = sps_csr((G.data, (G.row, m[G.col])), shape=(nd * gfaces.size, ora[k].shape[1]))
+            if reference:
+                ref_rows[-1][k] = Gl.copy()
             err = rel_max_err(Gl, ora[k][ex(lfaces)])
             worst[k] = max(worst.get(k, 0.0), err)
             assert err < TOL, (k, c0, err)
         checked += lfaces.size
-    return {"patches": len(targets), "rows_checked": checked, "worst_rel_err": worst}
+    out = {"patches": len(targets), "rows_checked": checked, "worst_rel_err": worst}
+    if reference:
+        # ---- the same rows against the REFERENCE ITSELF: pp.Mpsa (numerics/fv/mpsa.py:121-529, python inverter) run on
+        # the same patches with the same geometry arrays and stiffness tensors
+        refs = reference_on_patches(ref_inputs, product=bool(lib.pfv_is_device_build()), keys=MPSA_KEYS)
+        out["reference_patches"] = 0 if refs is None else len(refs)
+        if refs is not None:
+            worst_ref = {}
+            for rows, ref in zip(ref_rows, refs):
+                for k in MPSA_KEYS:
+                    Rl = sps_csr(ref[k][rows["rows"]])
+                    err = rel_max_err(rows[k], Rl)
+                    worst_ref[k] = max(worst_ref.get(k, 0.0), err)
+                    assert err < TOL, ("reference", k, err)
+                    # what the reference stores is stored here (its sparse products drop exact zeros: subset)
+                    stored = lambda mm: sps_csr((np.ones(mm.indices.size, np.int8), mm.indices, mm.indptr), shape=mm.shape)  # noqa: E731
+                    Gs, Rs = sps_csr(rows[k]), Rl
+                    Gs.sort_indices(); Rs.sort_indices()
+                    Dm = stored(Rs) - stored(Gs)
+                    assert Dm.nnz == 0 or Dm.max() <= 0, ("the reference stores an entry the device pattern lacks", k)
+            out["worst_rel_err_vs_reference"] = worst_ref
+    return out
 
 
 def split_matches_one_piece(lib, g, K, bc, bv, split_kwargs, monkeypatch=None, free=None):
@@ -1950,6 +1980,19 @@ def batch_matches_single(lib):
         Ab, bb = db.assemble_matrix_rhs(g, dat_b)
         As, bs_ = ds.assemble_matrix_rhs(g, dat_s)
         assert rel_max_err(Ab, As) < 1e-14 and np.allclose(bb, bs_, rtol=0, atol=1e-14)
+        # ... also with a vector source (ambient coordinates for the planes discretized with ambient_dimension 3:
+        # the union's matrices carry the lift already, the split path must not project the source a second time)
+        vdim = dat_b[pa.PARAMETERS]["flow"].get("ambient_dimension", g.dim)
+        vs = np.random.default_rng(11 + g.num_cells).standard_normal(vdim * g.num_cells)
+        dat_b[pa.PARAMETERS]["flow"]["vector_source"] = vs
+        dat_s[pa.PARAMETERS]["flow"]["vector_source"] = vs.copy()
+        Ab, bb = db.assemble_matrix_rhs(g, dat_b)
+        As, bs_ = ds.assemble_matrix_rhs(g, dat_s)
+        assert float(np.abs(bs_).max()) > 0.0
+        assert rel_max_err(Ab, As) < 1e-14 and np.allclose(bb, bs_, rtol=0, atol=1e-13 * max(1.0, float(np.abs(bs_).max()))), g.name
+        xb, _ = db.solve(g, dat_b, rtol=1e-12)
+        xs, _ = ds.solve(g, dat_s, rtol=1e-12)
+        assert np.allclose(xb, xs, rtol=0, atol=1e-8 * max(1.0, float(np.abs(xs).max()))), g.name
     return stats
 
 

@@ -116,8 +116,11 @@ def test_full_size_rows_match_oracle_on_patches(lib):
 def test_config_c3_all_four_matrices_on_patches(lib):
     """BASELINE configs[3] at full size: stress, bound_stress and both displacement-trace matrices on 18 patches
     (box corners where roller / traction / free faces meet, side centres, random cells)."""
-    out = P.mpsa_patch_parity_all_matrices(lib, 44)
+    out = P.mpsa_patch_parity_all_matrices(lib, 44, reference=True)
     assert out["patches"] >= 18 and out["rows_checked"] > 1000
+    # ... and against the REFERENCE ITSELF: pp.Mpsa (byte-compiled archive oracle/_ref) run on the same 18 patches
+    assert out["reference_patches"] == out["patches"], "reference archive oracle/_ref/porepy_ref.zip missing on the GPU box"
+    assert max(out["worst_rel_err_vs_reference"].values()) < 1e-10
 
 
 @pytest.mark.parametrize("name", ["mpsasub_cart2d_4x3", "mpsasub_tri2d_3x3_rob", "mpsasub_tet3d_2x2x2"])

@@ -368,6 +368,21 @@ def test_timed_bench_grid_all_matrices_on_patches(lib):
     assert out["patterns_bit_exact_vs_reference"] == 2 * out["patches"]  # flux + vector_source stencils, index for index
 
 
+def test_whole_headline_grid_against_the_recorded_reference_run(lib):
+    """Whole-grid datum at BASELINE configs[2] size: the reference itself was run on all 1 971 054
+    tetrahedra of make_problem(69) (`bench.py --cpu-headline 12`: 358 s of host time; record under profiles/).  The
+    device's flux matrix on the same grid must hold EXACTLY as many entries as the reference stored (the patterns are
+    compared index for index on patches above; this extends "bit-exact" to the entry count of the whole grid), and
+    the pressure field's norm must agree to what the reference's own Krylov residual (1e-10) allows."""
+    import bench
+
+    out = bench.whole_grid_check(pa, 0, 1e-13, "amg")
+    assert out["cells"] == 1971054
+    assert out["flux_nnz_device"] == out["flux_nnz_reference"] == 223875306, out
+    assert out["device_rel_residual"] < 1e-12
+    assert out["p_norm_rel_diff"] < 1e-7, out
+
+
 def test_config_c2_all_matrices_on_patches(lib):
     """BASELINE configs[1] (196 608 tetrahedra, isotropic): six matrices + A on 20 patches, exact linear field."""
     out = P.config_c2_patch_parity(lib, 32)
