@@ -421,17 +421,24 @@ def cached_cpu_headline():
     return out
 
 
-def whole_grid_check(pa, device_index: int, rtol: float, precond: str):
-    """Whole-grid parity datum at the headline size: the grid of the RECORDED reference run
-    (``oracle/ref_cpu_baseline.py 69 12``: make_problem(69) -- 1 971 054 tetrahedra, rng-perturbed nodes, log-normal
-    full-tensor K, unit source; ``profiles/r05_cpu_baseline_headline_grid_cached.json``) discretized, assembled and
-    solved on the device: nnz(flux) must EQUAL the reference's stored count (the structural stencil is the reference's
-    stored pattern on generic inputs), and the norm of the pressure field is compared with the reference's (whose own
-    Krylov solve stopped at a true residual of 1e-10)."""
-    with open(REFERENCE_HEADLINE_RUN) as fh:
-        rec = json.load(fh)["cpu_baseline_headline_grid"]
+HEADLINE_PATTERN = os.path.join(ROOT, "tests", "golden", "headline_flux_pattern_69.npz")
+
+
+def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_pattern: bool = False):
+    """Whole-grid parity datum at the headline size.  The REFERENCE was run on all 1 971 054
+    tetrahedra of make_problem(69) (``oracle/gen_golden_headline_pattern.py``: pp.Mpfa with 12 sub-problems, 20 minutes
+    of host time; the same topology and geometry arrays the device gets) and left, in
+    tests/golden/headline_flux_pattern_69.npz, the number of entries it STORES in every one of the 3 970 674 rows of
+    ``flux`` and a digest of their (row, column) pairs.  Here: the device's flux pattern on the same grid must have
+    exactly those row lengths in every row that is not a Neumann boundary row (where the true entries are all zero
+    and what either side stores is cancellation noise: there the reference's stored entries are a subset)."""
+    z = np.load(HEADLINE_PATTERN)
+    tot = json.loads(str(z["totals"]))
     t0 = time.perf_counter()
     g, K, bc, bv, src = make_problem(69)
+    nf = g.num_faces
+    ref_len = z["row_len"].astype(np.int64)
+    neu = np.unpackbits(z["neumann_row"])[:nf].astype(bool)
     ctx = pa.Context(device_index)
     try:
         ctx.set_grid(pa.grid_to_raw(g))
@@ -439,20 +446,30 @@ def whole_grid_check(pa, device_index: int, rtol: float, precond: str):
         ctx.discretize(rebuild_topology=True)
         ctx.assemble(bv, None, src)
         x, info = ctx.solve("bicgstab", rtol=rtol, maxit=20000, raise_on_fail=False, precond=precond)
-        nnz_flux = int(ctx.matrix_info(pa._lib.MAT_FLUX)[2])
+        F = ctx.matrix(pa._lib.MAT_FLUX)
         nnz_sys = int(ctx.matrix_info(pa._lib.MAT_SYSTEM)[2])
     finally:
         ctx.close()
-    pn = float(np.linalg.norm(x))
-    return {"grid": "make_problem(69): the grid of the recorded reference run (not the timed one: same lattice and "
-                    "stencil, nodes and K drawn from numpy's generator as oracle/ref_cpu_baseline.py does)",
-            "cells": int(g.num_cells), "flux_nnz_device": nnz_flux, "flux_nnz_reference": int(rec["flux_nnz"]),
-            "flux_nnz_equal": nnz_flux == int(rec["flux_nnz"]), "system_nnz_device": nnz_sys,
-            "p_norm_device": pn, "p_norm_reference": float(rec["check_norm"]),
-            "p_norm_rel_diff": abs(pn - float(rec["check_norm"])) / float(rec["check_norm"]),
-            "reference_solve": "scipy BiCGStab + Jacobi stopped at a true relative residual of 9.8e-11",
-            "device_iterations": int(info["iterations"]), "device_rel_residual": float(info["rel_residual"]),
-            "seconds_incl_host_grid": time.perf_counter() - t0}
+    dev_len = np.diff(F.indptr).astype(np.int64)
+    out = {"grid": "make_problem(69): 1 971 054 tetrahedra, the grid the reference was run on as a whole "
+                   "(oracle/gen_golden_headline_pattern.py; same lattice and stencil as the timed grid, nodes and K "
+                   "drawn from numpy's generator)",
+           "cells": int(g.num_cells), "faces": int(nf),
+           "flux_nnz_device": int(F.nnz), "flux_nnz_reference": int(tot["flux_nnz"]),
+           "rows_outside_neumann_boundary": int((~neu).sum()),
+           "flux_nnz_outside_neumann_rows_device": int(dev_len[~neu].sum()),
+           "flux_nnz_outside_neumann_rows_reference": int(tot["flux_nnz_outside_neumann_rows"]),
+           "rows_with_a_different_length_outside_neumann_rows": int((dev_len[~neu] != ref_len[~neu]).sum()),
+           "neumann_rows_where_the_reference_stores_more": int((ref_len[neu] > dev_len[neu]).sum()),
+           "system_nnz_device": nnz_sys, "p_norm_device": float(np.linalg.norm(x)),
+           "device_iterations": int(info["iterations"]), "device_rel_residual": float(info["rel_residual"]),
+           "reference_discretize_s_on_the_build_host": tot["discretize_s"],
+           "seconds_incl_host_grid": time.perf_counter() - t0}
+    out["pattern_row_lengths_equal"] = (out["rows_with_a_different_length_outside_neumann_rows"] == 0 and
+                                        out["neumann_rows_where_the_reference_stores_more"] == 0)
+    if want_pattern:
+        out["_pattern"] = (F.indptr, F.indices, ~neu, int(z["digest_rows"][0]))
+    return out
 
 
 def source_hash() -> str:
@@ -971,6 +988,7 @@ def main():
     if rank == 0 and world == 1 and not args.force_sharded and args.n_side == 69 and not args.no_whole_grid_check:
         try:
             whole_grid = whole_grid_check(pa, local_rank, args.rtol, args.precond)
+            whole_grid.pop("_pattern", None)
         except Exception as e:  # diagnostics only
             whole_grid = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.force_sharded and args.n_side == 69 and not args.no_extra_configs:

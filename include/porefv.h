@@ -125,6 +125,9 @@ typedef struct {
                                      included, its setup excluded (this library's own kernels; rocPRIM primitives, memsets
                                      and copies are not counted) */
   int64_t amg_setup_launches;     /* ... of the last preconditioner setup */
+  int64_t node_redo;              /* interaction regions the first launch of the last discretization handed to the
+                                     pivoted full body: those whose unpivoted elimination failed its a-posteriori check
+                                     (PFV_NODE_GJ=5), or whose condition asked for refinement in a lean launch */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);

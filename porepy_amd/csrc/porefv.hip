@@ -166,6 +166,13 @@ pfv_status pfv_create(int device, pfv_ctx** out) {
     PFV_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = h->stream;
     PFV_HIP_CHECK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    {
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+        if (hipStreamCreateWithPriority(&h->low_stream, hipStreamNonBlocking, least) != hipSuccess) h->low_stream = nullptr;
+      }
+      (void)hipGetLastError();
+    }
 #endif
   } catch (...) {
     delete h;
@@ -182,14 +189,16 @@ void pfv_destroy(pfv_ctx* h) {
   if (h->stream) {
     (void)hipStreamSynchronize(h->stream);
   }
-  hipStream_t s = h->own_stream, s2 = h->aux_stream;
+  hipStream_t s = h->own_stream, s2 = h->aux_stream, s3 = h->low_stream;
   if (s2) (void)hipStreamSynchronize(s2);
+  if (s3) (void)hipStreamSynchronize(s3);
   {
     pfv::PoolScope pool_scope(&h->pool);
     delete h;
   }
   if (s) (void)hipStreamDestroy(s);
   if (s2) (void)hipStreamDestroy(s2);
+  if (s3) (void)hipStreamDestroy(s3);
 #else
   {
     pfv::PoolScope pool_scope(&h->pool);
@@ -364,11 +373,14 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
       // symbolic kernels.  Its buffers live in the handle (nothing it touches passes through the block
       // cache while the other stream runs); the status words of the two phases are disjoint.
       if (h->aux_stream && pfv::env_int("PFV_OVERLAP_NODE", 1) != 0) {
-        pfv::StreamFork fork(s, h->aux_stream);   // aux waits for everything enqueued on s so far
+        // (PFV_NODE_LOWPRIO=1: on the handle's lowest-priority stream -- the symbolic kernels, short and many, then win
+        // the dispatch slots the long kernel frees instead of queueing behind its ~300 k wavefronts)
+        pfv::stream_t ns = (h->low_stream && pfv::env_int("PFV_NODE_LOWPRIO", 0) != 0) ? h->low_stream : h->aux_stream;
+        pfv::StreamFork fork(s, ns);   // ns waits for everything enqueued on s so far
         pfv::Timer tn;
-        tn.start(h->aux_stream);
-        pfv::launch_node_kernel(*h, nullptr, h->aux_stream);
-        tn.mark(h->aux_stream);
+        tn.start(ns);
+        pfv::launch_node_kernel(*h, nullptr, ns);
+        tn.mark(ns);
         tm.start(s);
         // (the pattern of A is only needed by the assembly: PFV_SYMB_DEFER_CELLS=1 builds it beside the face kernel,
         // below -- measured: interaction-region span 14.2 -> 13.2 ms, face span 7.2 -> 9.1 ms, step +0.5 ms: off)

@@ -1908,7 +1908,9 @@ def sliver_refinement(lib):
         return e1, e2
 
     off, on = errs("-1"), errs("0")
-    assert off[0] > 5e-9 and off[1] > 5e-9, off  # the fixtures do exercise the path
+    # the fixtures do exercise the path: without it both are an order of magnitude beyond the 1e-10 gate (how far
+    # beyond is rounding noise times a condition number of ~1e7: 2e-8 ... 3e-9 from build to build)
+    assert off[0] > 1e-9 and off[1] > 1e-9, off
     assert on[0] < SLIVER_TOL and on[1] < SLIVER_TOL and max(on) < 0.05 * min(off), (on, off)
     return off, on
 
