@@ -148,6 +148,7 @@ def bench_config_c4(pa, device_index: int, rtol: float, precond: str, steps: int
             "roofline_node_kernel": node_roofline,
             "value": nc / dt, "unit": "cells/s", "ms_per_step": 1e3 * dt, "steps": steps, "dofs": 3 * nc,
             "iterations": info["iterations"], "krylov": "bicgstab+" + precond,
+            "node_redo": int(st.get("node_redo", 0)),
             "max_abs_error_vs_exact_uniaxial_field": err,
             "phases_ms": {k: st[k] for k in ("topology_ms", "symbolic_ms", "node_ms", "face_ms", "assemble_ms",
                                              "solve_ms")}}

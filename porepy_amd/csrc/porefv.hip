@@ -1496,7 +1496,7 @@ pfv_status pfv_amg_setup_sharded(pfv_ctx* h, int64_t n_own, const pfv_shard_hook
     h->stats.amg_operator_complexity = amg.op_complexity;
     h->stats.amg_levels = (int64_t)(amg.nlev + (amg.dist->glob ? amg.dist->glob->nlev - 1 : 0));
     h->stats.amg_coarsest_rows = amg.dist->gN;
-    h->stats.amg_maps_reused = 0;
+    h->stats.amg_maps_reused = amg.reused ? 1 : 0;
   });
 }
 
