@@ -90,6 +90,7 @@ struct pfv_ctx_impl {
   stream_t own_stream{};  // the stream created with the handle (stream may point elsewhere, pfv_set_stream)
   Buf<double> sys_rowmax;            // largest off-diagonal |a_ij| of every row of A, left by assemble_system
   const double* sys_rowmax_for = nullptr;  // ... for this value array (nullptr: none)
+  bool face_order_cell_major = false;  // face_order: faces of one first-side cell back to back (PFV_FACE_ORDER / PFV_FACE_CACHE)
   stream_t low_stream{};  // a stream of the LOWEST priority the device offers (PFV_NODE_LOWPRIO: the interaction-region
                           // kernel goes there, so that the short symbolic kernels beside it are dispatched first)
   stream_t aux_stream{};  // second stream of the handle: the interaction-region kernel runs there while the

@@ -1686,6 +1686,22 @@ pfv_status pfv_solve_sharded(pfv_ctx* h, int method, double rtol, int maxit, int
               "pfv_amg_setup(n_own) first: the sharded solve preconditions with the hierarchy of the owned block");
       M.amg = h->amg_block.get();
       Mp = &M;
+    } else if (h->precond == PFV_PRECOND_BLOCK) {
+      // block lower-triangular sweep over the blocks of the OWNED unknowns (pfv_set_block_preconditioner with a layout
+      // that covers [0, n_own)): couplings to other ranks' unknowns are left to the Krylov loop (block Jacobi across
+      // ranks, Gauss-Seidel over the (variable, subdomain) blocks inside a rank) -- every diagonal block is extracted
+      // from the owned rows and columns, the halo columns lie behind them and never enter a block or its sweep
+      require(h->block_pc != nullptr, "pfv_set_block_preconditioner first");
+      require(h->block_pc->ptr.back() == n_own, "the block layout must cover exactly the owned unknowns");
+      if (h->block_pc->for_val != sys.val) {
+        pfv::blockpc_setup(*h, *h->block_pc, rows.V, sys.val);
+        h->stats.amg_setup_ms = h->block_pc->setup_ms;
+      }
+      M.blocks = h->block_pc.get();
+      M.P = &rows.V;
+      M.val = sys.val;
+      M.diag = sys.diag;
+      Mp = &M;
     }
     pfv::be_memset(d_x_owned, 0, sizeof(double) * (size_t)n_own, s);
     pfv::be_memset(d_work, 0, sizeof(double) * (size_t)(2 * n_loc + 8), s);

@@ -659,8 +659,10 @@ class ShardedMpfa:
     def _solve_library(self, method, rtol, maxit, precond):
         torch = self.torch
         n, nloc, dev = self.n_own, self.n_loc, self.device
-        if precond not in ("jacobi", "amg", "amg_block"):
-            raise ValueError("precond must be 'jacobi', 'amg' or 'amg_block'")
+        if precond not in ("jacobi", "amg", "amg_block", "block"):
+            raise ValueError("precond must be 'jacobi', 'amg', 'amg_block' or 'block'")
+        if precond == "block" and not getattr(self, "_block_layout_set", False):
+            raise ValueError("precond='block': set_block_preconditioner(block_ptr over the owned unknowns) first")
         import os
 
         native = self.rccl_transport() if os.environ.get("PFV_SHARDED_TRANSPORT", "rccl") == "rccl" else None
@@ -807,6 +809,16 @@ class ShardedCsr(ShardedMpfa):
         self._b = self._diag = None
         self._amg_ready = False
         self.owned_gid = own
+
+    def set_block_preconditioner(self, block_ptr, gauss_seidel: bool = True):
+        """Blocks [block_ptr[k], block_ptr[k+1]) of the OWNED unknowns (local numbering, covering [0, n_own)): the
+        sharded solve with ``precond="block"`` sweeps them lower-triangularly with one AMG hierarchy (or exact dense
+        inverse) per block; couplings to the unknowns of other ranks are left to the Krylov loop."""
+        bp = np.asarray(block_ptr, dtype=np.int64)
+        if bp[0] != 0 or bp[-1] != self.n_own:
+            raise ValueError("the block layout must cover exactly the owned unknowns")
+        self.ctx.set_block_preconditioner(bp, gauss_seidel)
+        self._block_layout_set = True
 
     def discretize(self, *a, **k):
         raise NotImplementedError("ShardedCsr takes an assembled system")

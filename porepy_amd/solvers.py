@@ -157,6 +157,79 @@ def solve_block_system(A, b, block_of, method: str = "gmres", rtol: float = 1e-1
     return x, info
 
 
+def solve_block_system_sharded(A, b, block_of, owner, dist, rtol: float = 1e-12, maxit: int = 5000, device: str = "cuda",
+                               local_device_index: int = 0, library=None, gauss_seidel: bool = True, row_perm=None,
+                               eliminate=None):
+    """:func:`solve_block_system` over the ranks of a process group: the unknowns are dealt out by
+    ``owner`` (by subdomain for a fracture network), every rank keeps the rows of its own unknowns
+    (:class:`porepy_amd.distributed.ShardedCsr`: halo plan over cell, fracture and mortar unknowns) and preconditions
+    with the block lower-triangular sweep over ITS (variable, subdomain) blocks -- block Jacobi across ranks,
+    Gauss-Seidel inside -- in the library's fused BiCGStab loop (``pfv_solve_sharded`` with PFV_PRECOND_BLOCK).  The
+    condensation of the interface fluxes (``eliminate``, see :func:`solve_block_system`) is formed by every rank for the
+    whole system on the host (two sparse products of a matrix that every rank holds anyway at this point: the
+    reference assembles its Jacobian on every process), then sharded.  Returns (x, info) with the full solution on every
+    rank, in the caller's numbering."""
+    import scipy.sparse as sps
+
+    from .distributed import ShardedCsr
+
+    A = sps.csr_matrix(A)
+    b = np.asarray(b, dtype=float)
+    n = A.shape[0]
+    block_of = np.asarray(block_of)
+    owner = np.asarray(owner)
+    perm = match_rows(A) if row_perm is None else np.asarray(row_perm, dtype=np.int64)
+    A1, b1 = (A, b) if perm is None else (A[perm], b[perm])
+    ids = list(np.unique(block_of))
+    if eliminate is not None:
+        eliminate = np.asarray(eliminate, dtype=bool)
+        gone = {int(k) for k in np.unique(block_of[eliminate])}
+        ids = [k for k in ids if int(k) not in gone] + [k for k in ids if int(k) in gone]
+        if not eliminate.any() or eliminate.all():
+            eliminate = None
+    rank_of = {int(k): i for i, k in enumerate(ids)}
+    key = np.array([rank_of[int(k)] for k in block_of])
+    order = np.argsort(key, kind="stable")
+    A2 = sps.csr_matrix(A1[order][:, order])
+    A2.sort_indices()
+    b2 = b1[order]
+    own2 = owner[order]
+    key2 = key[order]
+    if eliminate is not None:
+        e2 = eliminate[order]
+        d = A2.diagonal()
+        if np.any(d[e2] == 0.0):
+            raise ValueError("eliminate: a condensed unknown has a zero diagonal entry (pair the rows first)")
+        coo = A2.tocoo()
+        pick = ~e2[coo.row] & e2[coo.col]
+        G = sps.csr_matrix((coo.data[pick] / d[coo.col[pick]], (coo.row[pick], coo.col[pick])), shape=(n, n))
+        A2 = sps.csr_matrix(A2 - G @ A2)
+        A2.sort_indices()
+        b2 = b2 - G @ b2
+    sh = ShardedCsr(A2, b2, own2, device=device, local_device_index=local_device_index, library=library, dist=dist)
+    mine = sh.owned_gid                      # ascending: sorted by block key
+    counts = np.bincount(key2[mine], minlength=len(ids))
+    ptr = np.concatenate(([0], np.cumsum(counts[counts > 0]))).astype(np.int64)
+    sh.set_block_preconditioner(ptr, gauss_seidel)
+    x_own, info = sh.solve("bicgstab", rtol=rtol, maxit=maxit, precond="block")
+    parts = [None] * (dist.get_world_size() if dist is not None else 1)
+    payload = (mine, np.asarray(x_own.cpu().numpy() if hasattr(x_own, "cpu") else x_own))
+    if dist is not None:
+        dist.all_gather_object(parts, payload)
+    else:
+        parts = [payload]
+    x2 = np.empty(n)
+    for idx, vals in parts:
+        x2[idx] = vals
+    x = np.empty(n)
+    x[order] = x2
+    info = dict(info)
+    info["blocks_here"] = int(ptr.size - 1)
+    info["condensed_unknowns"] = 0 if eliminate is None else int(eliminate.sum())
+    info["true_rel_residual"] = float(np.linalg.norm(b - A @ x) / max(np.linalg.norm(b), 1e-300))
+    return x, info
+
+
 def pair_equation_blocks(A, row_blocks, col_blocks):
     """Pair equation blocks with variable blocks of a coupled Jacobian.  ``row_blocks`` / ``col_blocks``: lists of
     ``(group, indices)`` -- group = the grid the equation / variable lives on; blocks of one group with equal sizes are

@@ -567,6 +567,59 @@ def test_sharded_thermo_hydro_mixed_dimensional_jacobian(tmp_path):
     assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
 
 
+def _block_sharded_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    import scipy.sparse as sps
+
+    from porepy_amd import solvers
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "md_thermal_jacobian_box_52fractures.npz"))
+        A = sps.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+        b, block_of, row_perm, intf = z["b"], z["block_of"], z["row_perm"], z["interface"].astype(bool)
+        n = A.shape[0]
+        # ownership by position inside every variable-wide block: the reference numbers a variable grid by grid (the
+        # 3-D matrix first, then the fracture planes, lines, points / the mortar grids), so equal shares of a block are
+        # runs of whole subdomains -- every rank holds a part of every variable (pressure, temperature, the three fluxes)
+        owner = np.zeros(n, dtype=np.int64)
+        for k in np.unique(block_of):
+            idx = np.flatnonzero(block_of == k)
+            owner[idx] = (np.arange(idx.size) * world) // idx.size
+        x, info = solvers.solve_block_system_sharded(A, b, block_of, owner, dist, rtol=1e-12, maxit=4000, device="cpu",
+                                                     library=P.emulation_library(), row_perm=row_perm, eliminate=intf)
+        torch.save({"x": x, "info": info}, os.path.join(out, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_block_solve_of_the_52_fracture_thermo_hydro_jacobian(tmp_path):
+    """the coupled thermo-hydro Jacobian of the 52-fracture model (21 360 unknowns: pressures,
+    temperatures and three families of interface fluxes on 190 subdomains and 385 interfaces) solved SHARDED at world
+    2: interface fluxes condensed, unknowns dealt out by runs of subdomains, the library's fused BiCGStab loop with the
+    block lower-triangular preconditioner over each rank's own blocks (pfv_solve_sharded + PFV_PRECOND_BLOCK), halo
+    exchange of cell and mortar unknowns through the hooks.  Same answer as the direct solution."""
+    import scipy.sparse as sps
+    import torch
+    import torch.multiprocessing as mp
+
+    world = 2
+    P.emulation_library()
+    mp.spawn(_block_sharded_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "md_thermal_jacobian_box_52fractures.npz"))
+    A = sps.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=tuple(z["shape"]))
+    x_ref = spla.spsolve(A.tocsc(), z["b"])
+    for r in range(world):
+        o = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"), weights_only=False)
+        assert o["info"]["converged"], o["info"]
+        assert o["info"]["condensed_unknowns"] == int(z["interface"].sum())
+        assert o["info"]["true_rel_residual"] < 1e-9, o["info"]
+        assert np.linalg.norm(o["x"] - x_ref) <= 1e-8 * np.linalg.norm(x_ref)
+
+
 def test_block_partition_covers_the_box_once():
     """bench.py's strong-scaling cut (`block_grid`, `make_slab_problem(blocks=...)`): the block grids are as cubic as
     possible, every lattice cell is owned by exactly one rank, halo cells name their owners, and 2 x 2 x 2 blocks carry

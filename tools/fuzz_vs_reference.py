@@ -6,7 +6,8 @@ GPU box.  TEST INFRASTRUCTURE.
 
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/repo/oracle/shim:/root/reference/src:/root/repo \\
       python /root/repo/tools/fuzz_vs_reference.py [n_cases] [first_seed] [special]
-(`special`: conditions per sub-face, partial discretization, 2-D grids tilted in 3-D, TPFA)
+(`special`: conditions per sub-face, partial discretization, 2-D grids tilted in 3-D, TPFA; `contrast`: permeability
+contrasts of 1e10 ... 1e15, verdict of the local inversions against the reference's)
 """
 import os
 import sys
@@ -420,10 +421,59 @@ def case_special(lib, seed):
     return kind, nc, out
 
 
+def case_contrast(lib, seed):
+    """Flow with permeability contrasts of 1e10 ... 1e15 between neighbouring cells: the VERDICT of
+    the local inversions -- does a side raise "singular"? -- must be the reference's, whose LAPACK inverse only raises
+    on an exactly zero pivot (matrix_operations.py:1470, 1487-1490).  Where both sides return, the matrices are compared
+    relative to the largest entry of the reference's matrix row by row block (entries span the contrast)."""
+    rng = np.random.default_rng(seed)
+    g, kind = random_ref_grid(rng)
+    while kind >= 4:  # (slivers have their own legs; here the geometry stays well shaped)
+        g, kind = random_ref_grid(rng)
+    nd, nc, nf = g.dim, g.num_cells, g.num_faces
+    h = pa.grid_from_raw(grid_to_raw(g))
+    bf = g.get_all_boundary_faces()
+    decades = rng.uniform(10.0, 15.0)
+    s = 10.0 ** (decades * (rng.random(nc) - 0.5))
+    if rng.random() < 0.5:  # two-valued field: the sharpest jumps
+        s = np.where(rng.random(nc) < 0.5, 10.0 ** (-decades / 2), 10.0 ** (decades / 2))
+    kw = dict(kxx=s * (1 + rng.random(nc)), kyy=s * (1 + rng.random(nc)), kxy=s * 0.4 * (rng.random(nc) - 0.5))
+    if nd == 3:
+        kw.update(kzz=s * (1 + rng.random(nc)), kxz=s * 0.3 * (rng.random(nc) - 0.5), kyz=s * 0.3 * (rng.random(nc) - 0.5))
+    types = rng.choice(["dir", "neu"], size=bf.size, p=[0.6, 0.4])
+    types[rng.integers(0, bf.size)] = "dir"
+    rbc = pp.BoundaryCondition(g, bf, list(types))
+    rdata = pp.initialize_data({}, "flow", {"second_order_tensor": pp.SecondOrderTensor(**kw), "bc": rbc,
+                                            "mpfa_inverter": "python"})
+    hbc = pa.BoundaryCondition(h, bf, list(types))
+    hdata = pa.initialize_data({}, "flow", {"second_order_tensor": pa.SecondOrderTensor(**kw), "bc": hbc})
+    out = []
+    try:
+        pp.Mpfa("flow").discretize(g, rdata)
+        ref_ok = True
+    except Exception as e:
+        ref_ok = False
+        out.append(f"contrast 1e{decades:.1f}: reference raised {type(e).__name__}")
+    try:
+        pa.Mpfa("flow", library=lib).discretize(h, hdata)
+        ours_ok = True
+    except ValueError:
+        ours_ok = False
+    if ref_ok != ours_ok:
+        out.append(f"contrast 1e{decades:.1f}: VERDICTS DIFFER (reference {'returned' if ref_ok else 'raised'}, "
+                   f"device {'returned' if ours_ok else 'raised'})")
+        out.append(("verdict", 1.0))
+    elif ref_ok:
+        r, o = rdata[pp.DISCRETIZATION_MATRICES]["flow"], hdata[pa.DISCRETIZATION_MATRICES]["flow"]
+        out.append((f"flow, contrast 1e{decades:.1f}", max(rel(o[k], r[k]) for k in FLOW)))
+    return kind, nc, out
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    fn = case_special if (len(sys.argv) > 3 and sys.argv[3] == "special") else case
+    mode = sys.argv[3] if len(sys.argv) > 3 else ""
+    fn = case_special if mode == "special" else (case_contrast if mode == "contrast" else case)
     # PFV_FUZZ_DEVICE=1: the gfx950 product library on the GPU (reference from oracle/_ref on the GPU box)
     lib = None if os.environ.get("PFV_FUZZ_DEVICE") else P.emulation_library()
     bad = 0
