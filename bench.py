@@ -422,6 +422,51 @@ def cached_cpu_headline():
     return out
 
 
+C5_RECORD = os.path.join(ROOT, "profiles", "r05_c5_32cube_52fractures.json")
+
+
+def config_c5(live: bool = False):
+    """BASELINE configs[4] stand-in at 32^3 (36 657 cells, 98 229 unknowns, 52 fractures, 190 subdomains, 301 interfaces):
+    the reference's thermo-hydro model with pp.Mpfa rebound to the library and every Newton system solved on the
+    device, beside the untouched reference (tools/c5_bench.py).  The live run takes ~5 minutes of host time (the
+    reference's direct solves): ``--c5``; by default the record of such a run on an MI355X box is carried."""
+    if live:
+        import subprocess
+
+        env = dict(os.environ, C5_N_SIDE="32", C5_MAX_EXTENT="14", PFV_DROPIN_LIBRARY="product")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c5_bench.py"), "--reference"], env=env,
+                           capture_output=True, text=True, timeout=3600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        if not line:
+            return {"error": (r.stderr or "no output")[-600:]}
+        d = json.loads(line[-1][7:])
+        live_rec = {"cached": False, "result": d}
+        if "error" in d.get("device", {}) or "reference" not in d or "error" in d["reference"]:
+            return live_rec
+        dev, ref = d["device"], d["reference"]
+        live_rec["per_newton_step_s"] = {
+            "device": {"assemble_host_ad": dev["seconds"]["assemble"] / dev["calls"]["n_assemble"],
+                       "linear_solve_device": dev["seconds"]["solve"] / dev["calls"]["n_solve"]},
+            "reference": {"assemble_host_ad": ref["seconds"]["assemble"] / ref["calls"]["n_assemble"],
+                          "linear_solve_scipy_direct": ref["seconds"]["solve"] / ref["calls"]["n_solve"]}}
+        live_rec["discretize_s"] = {"device_all_190_subdomains": dev["seconds"]["discretize"],
+                                    "reference": ref["seconds"]["discretize"]}
+        return live_rec
+    try:
+        with open(C5_RECORD) as fh:
+            rec = json.load(fh)
+    except Exception:
+        return None
+    dev, ref = rec["result"]["device"], rec["result"]["reference"]
+    return {"cached": True, "record": os.path.relpath(C5_RECORD, ROOT), "measured": rec["command"], "workload": rec["workload"],
+            "cells": dev["cells"], "dofs": dev["dofs"], "subdomains": dev["subdomains"], "interfaces": dev["interfaces"],
+            "per_newton_step_s": rec["per_newton_step_s"], "discretize_s": rec["discretize_s"],
+            "newton_systems": dev["calls"]["n_solve"], "gmres_iterations": dev["gmres_iterations"],
+            "worst_true_residual": dev["worst_true_residual"],
+            "x_rel_diff_device_vs_reference": rec["result"]["x_rel_diff_device_vs_reference"],
+            "reference_source_digest_here": reference_source_digest()}
+
+
 HEADLINE_PATTERN = os.path.join(ROOT, "tests", "golden", "headline_flux_pattern_69.npz")
 
 
@@ -490,7 +535,7 @@ def load_pmc(n_side: int, world: int) -> dict:
     """HBM traffic per launch from the PMC passes of tools/gpu_pmc.sh (FETCH_SIZE and WRITE_SIZE in separate
     runs), if profiles/ holds a file collected with exactly this build on this workload; else {}."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as fh:
             pj = json.load(fh)
         if pj.get("n_side") == n_side and world == 1 and pj.get("source_hash") == source_hash():
             return pj["kernels"]
@@ -611,6 +656,9 @@ def main():
                     help="also time the reference on the HEADLINE grid itself (configs[2] size) with "
                          "partition_arguments={'num_subproblems': K} (SURVEY 8(d)); minutes of host time: off by default, "
                          "the record of such a run is kept under profiles/")
+    ap.add_argument("--c5", action="store_true",
+                    help="run the configs[4] stand-in (52 fractures, 32^3) live: device-backed model and the reference, "
+                         "~5 minutes; by default the bench line carries the record under profiles/")
     ap.add_argument("--fixed-k", action="store_true",
                     help="repeat the step on ONE permeability field (rounds 1-4) instead of a new field per step")
     ap.add_argument("--no-cold", action="store_true", help="skip the secondary figure ms_per_step_cold")
@@ -727,14 +775,20 @@ def main():
         # as above: a new log-normal factor per step, a function of the GLOBAL cell ids (one global field on all ranks)
         n_fields = 1 if args.fixed_k else min(32, 6 + args.warmup + args.steps + 1)
         base_scale = np.exp(0.5 * _hash_normal(lp.cell_gid, 7))
-        k_aniso = Kvals / base_scale[None, None, :]
-        k_fields = [Kvals] + [np.ascontiguousarray(k_aniso * np.exp(0.5 * _hash_normal(lp.cell_gid, 1000 + 2 * i))[None, None, :])
-                              for i in range(1, n_fields)]
+        d_aniso = torch.from_numpy(np.ascontiguousarray(Kvals / base_scale[None, None, :])).to(devs)
+        fields = [base_scale] + [np.exp(0.5 * _hash_normal(lp.cell_gid, 1000 + 2 * i)) for i in range(1, n_fields)]
+        d_fac = torch.from_numpy(np.ascontiguousarray(np.stack(fields))).to(devs)
+        d_K = torch.empty_like(d_aniso)
+        del fields
         step_no = [0]
+        # (conditions and eta go up once, with host arrays; every step then replaces the permeability device to device)
+        sh.discretize(Kvals, flags, None, eta, skip_vector_source=False, rebuild_topology=True)
+        torch.cuda.synchronize()
 
         def step():
             step_no[0] += 1
-            sh.discretize(k_fields[step_no[0] % n_fields], flags, None, eta, skip_vector_source=False, rebuild_topology=True)
+            torch.mul(d_aniso, d_fac[step_no[0] % n_fields][None, None, :], out=d_K)
+            sh.discretize(d_K, flags, None, eta, skip_vector_source=False, rebuild_topology=True)
             sh.assemble(d_bv, d_src)
             return sh.solve("bicgstab", rtol=args.rtol, maxit=20000, precond=args.precond, driver=drv)
 
@@ -1085,6 +1139,7 @@ def main():
             "whole_grid_check": whole_grid,
             "assembly": assembly, "operator_api": opapi, "cpu_baseline": cpu, "cpu_baseline_headline_grid": cpu_headline,
             "config_c2": c2, "config_c4": c4,
+            "config_c5": (config_c5(args.c5) if (world == 1 and args.n_side == 69 and (args.c5 or not args.no_extra_configs)) else None),
         }
         if args.phases:
             print(json.dumps(st, indent=1), file=sys.stderr)

@@ -268,7 +268,20 @@ class ShardedMpfa:
 
     def discretize(self, perm_local, bc_flags_local, robin_local=None, eta=0.0, skip_vector_source=True,
                    rebuild_topology=False):
-        self.ctx.set_params(perm_local, bc_flags_local, robin_local, eta)
+        """``perm_local``: (3, 3, n_local) numpy array -- or a torch tensor resident on this rank's device: then only
+        the permeability is replaced, device to device (pfv_mpfa_set_permeability), and the conditions / eta of the
+        last call with host arrays are kept (no PCIe traffic in the step)."""
+        torch = self.torch
+        if isinstance(perm_local, torch.Tensor):
+            if not getattr(self, "_params_set", False):
+                raise ValueError("the first discretize call takes host arrays (conditions, eta); later ones may pass a device tensor")
+            if tuple(perm_local.shape) != (3, 3, self.n_loc) or perm_local.dtype != torch.float64 or not perm_local.is_contiguous():
+                raise ValueError("permeability tensor: contiguous float64 of shape (3, 3, n_local)")
+            self._use_torch_stream()
+            self.ctx.set_permeability_device(perm_local.data_ptr())
+        else:
+            self.ctx.set_params(perm_local, bc_flags_local, robin_local, eta)
+            self._params_set = True
         self.ctx.discretize(rebuild_topology=rebuild_topology, skip_vector_source=skip_vector_source)
 
     def assemble(self, bc_values_local, source_local=None):

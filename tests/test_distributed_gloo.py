@@ -74,6 +74,7 @@ def _worker(rank, world, port, kind, method, out, precond="jacobi"):
         # solve is as good -- K -> 2 K with the Dirichlet data kept and the sources doubled leaves the pressure as it was
         reused = None
         x2 = None
+        os.environ["PFV_AMG_REUSE_DIST_MIN_ROWS"] = "1"  # (the default keeps the maps of large shares only)
         if precond == "amg":
             sh.discretize(2.0 * K.values[:, :, lp.cell_gid], flags, bc.robin_weight[lp.face_gid], pa.determine_eta(g))
             sh.assemble(bv[lp.face_gid], 2.0 * src[lp.cell_gid])
