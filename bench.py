@@ -819,8 +819,11 @@ def main():
         x, info = step()
     barrier()
     t0 = time.perf_counter()
+    each = []   # (the solve call returns once the host has read its iteration count: a step is synchronous)
     for _ in range(args.steps):
+        ts = time.perf_counter()
         x, info = step()
+        each.append((1e3 * (time.perf_counter() - ts), int(info["iterations"]) if isinstance(info, dict) and "iterations" in info else -1))
     ctx.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -1131,6 +1134,9 @@ def main():
             "roofline": roofline, "roofline_kernels": kernels[1:], "kernel_ms_per_step": per_step_ms,
             "hbm_triad_measured_GBs": triad_gbs, "hbm_read_stream_measured_GBs": read_gbs,
             "ms_per_step_cold": (cold or {}).get("ms_per_step_cold"), "cold_step": cold,
+            "each_timed_step": {"ms": [round(t, 2) for t, _ in each[:64]], "iterations": [i for _, i in each[:64]],
+                                "note": "rank 0; the permeability field differs from step to step, and so do the iteration "
+                                        "count and the sizes of everything the strength filter produces"},
             "permeability_per_step": ("one field repeated (--fixed-k)" if args.fixed_k else
                                       f"a new log-normal field every step ({n_fields} fields resident in HBM, cycled)"),
             "launches_per_iteration": (st.get("solve_launches", 0) / max(its, 1)) if its else None,

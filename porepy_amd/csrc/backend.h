@@ -290,13 +290,18 @@ struct Buf {
   Buf(const Buf&) = delete;
   Buf& operator=(const Buf&) = delete;
   ~Buf() { be_free(p); }
+  // A buffer that has to grow a SECOND time takes an eighth of head room: sizes that follow the values (entries the
+  // strength filter keeps, Galerkin products) move by a few per cent from step to step, and every growth of a
+  // few-hundred-MB block is a hipMalloc of milliseconds inside the step (measured on coefficients that change every
+  // step: 10 ms per step over the first steps of a run, until every buffer had seen its largest size).
   T* ensure(size_t n) {
     if (n > cap) {
+      const size_t want = cap > 0 ? std::max(n, cap + cap / 8) : n;
       be_free(p);
       p = nullptr;
       cap = 0;
-      p = static_cast<T*>(be_malloc(n * sizeof(T)));
-      cap = n;
+      p = static_cast<T*>(be_malloc(want * sizeof(T)));
+      cap = want;
     }
     return p;
   }

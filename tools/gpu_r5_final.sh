@@ -28,4 +28,17 @@ bash tools/gpu_trace_bench.sh > $O/trace_stdout.log 2>&1; cp gpurun_out/bench_ke
 bash tools/gpu_pmc.sh > $O/pmc_stdout.log 2>&1
 cp gpurun_out/pmc_summary.txt $O/pmc_summary.txt; cp gpurun_out/pmc_traffic.json $O/pmc_traffic.json; cat $O/pmc_traffic.json | head -40; stamp pmc
 rm -rf gpurun_out/btrace
+# the randomized differential driver on the device against the reference itself (archive oracle/_ref)
+ENVF=$(python - <<'PY'
+import oracle
+e = oracle.ref_env(extra_last=["."], prefer_archive=True)
+print(e["PYTHONPATH"] if e else "")
+PY
+)
+if [ -n "$ENVF" ]; then
+  (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH="$ENVF:$R" timeout 600 python $R/tools/fuzz_vs_reference.py 40 918273 > $R/$O/fuzz_device_vs_reference.log 2>&1; tail -2 $R/$O/fuzz_device_vs_reference.log)
+  (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH="$ENVF:$R" timeout 600 python $R/tools/fuzz_vs_reference.py 30 555111 special > $R/$O/fuzz_device_vs_reference_special.log 2>&1; tail -2 $R/$O/fuzz_device_vs_reference_special.log)
+  (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH="$ENVF:$R" timeout 600 python $R/tools/fuzz_vs_reference.py 40 7000 contrast > $R/$O/fuzz_device_vs_reference_contrast.log 2>&1; tail -2 $R/$O/fuzz_device_vs_reference_contrast.log)
+fi
+stamp fuzz
 cat $O/timeline.log
