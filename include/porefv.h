@@ -357,8 +357,12 @@ pfv_status pfv_mpsa_set_subface_eta(pfv_ctx* h, const double* eta_subface);
  * traces (bound_displacement_cell / bound_displacement_face) are reconstructed at x_f + hf_eta (x_v - x_f) from the
  * sub-cell gradients, averaged over the two sides of the sub-face, instead of at the continuity points (a scalar: 0
  * on boundary faces, as the reference's distance routine does).  on = 0 switches back.  After pfv_mpsa_set_params
- * (which clears it).  Not combined with the Biot coupling terms or conditions per sub-face (PFV_ERR_UNSUPPORTED). */
+ * (which clears it).  Not combined with the Biot coupling terms (PFV_ERR_UNSUPPORTED). */
 pfv_status pfv_mpsa_set_reconstruction_eta(pfv_ctx* h, int on, double hf_eta);
+/* the same with one value per sub-face (compute_dist_face_cell with an array, numerics/fv/_fvutils.py:222-277: used as
+ * given, also on the boundary), sub-faces in the order of the sorted face_nodes CSC arrays; NULL switches the
+ * reconstruction points back to the continuity points. */
+pfv_status pfv_mpsa_set_reconstruction_eta_subface(pfv_ctx* h, const double* hf_eta_subface);
 /* Robin conditions of the vectorial boundary condition (BoundaryConditionVectorial.is_rob,
  * .robin_weight, params/bc.py:222-322; rows of numerics/fv/mpsa.py:1381-1459): bit c of
  * bc_rob_bits[f] = component c of face f is Robin; robin_weight_ddn = weights W[i][a][f], shape
@@ -380,10 +384,15 @@ pfv_status pfv_mpsa_set_basis(pfv_ctx* h, const double* basis_ddn);
  *   PFV_MAT_BOUND_DISPLACEMENT_CELL  (nd Nf  x nd Nc)    as with conditions per face
  *   PFV_MAT_BOUND_DISPLACEMENT_FACE  (nd Nf  x nd Nsf)
  * and pfv_mpsa_assemble refuses (the caller collapses the sub-face rows first, as with the reference).
- * bc_dir_bits_sub = NULL returns to conditions per face; pfv_mpsa_set_params resets it.  Not combined with a
- * face-wise basis, Biot coupling terms or partial updates. */
+ * bc_dir_bits_sub = NULL returns to conditions per face; pfv_mpsa_set_params resets it.  Not combined with
+ * Biot coupling terms or partial updates; a basis comes per sub-face too (pfv_mpsa_set_subface_basis). */
 pfv_status pfv_mpsa_set_subface_bc(pfv_ctx* h, const uint8_t* bc_dir_bits_sub, const uint8_t* bc_neu_bits_sub,
                                    const uint8_t* bc_rob_bits_sub, const double* robin_weight_dds);
+/* the basis of conditions per sub-face (the .basis of a BoundaryConditionVectorial with one entry per sub-face,
+ * numerics/fv/_fvutils.py:836-852 through ExcludeBoundaries.basis_matrix): shape (nd, nd, Nsf) C-order, sub-faces in
+ * the order of the sorted face_nodes CSC arrays; NULL = Cartesian.  Call after pfv_mpsa_set_subface_bc (which
+ * resets it). */
+pfv_status pfv_mpsa_set_subface_basis(pfv_ctx* h, const double* basis_dds);
 
 /* Mpsa._stress_discretization (numerics/fv/mpsa.py:531-782) on the device; fills matrices 7-10 */
 pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags);

@@ -25,7 +25,7 @@ from oracle.gen_golden_mpsa import KEYS, vec_bc  # noqa: E402
 from oracle.ref_bridge import grid_to_raw  # noqa: E402
 
 
-def save(name, g, C, bc_face, rng, robin=False):
+def save(name, g, C, bc_face, rng, robin=False, basis=False, hf_eta=None):
     # sub-face ids are positions in the stored face_nodes arrays: fix the storage order first so that the
     # reference numbers sub-faces like the raw (sorted) arrays of the fixture
     g.face_nodes.sort_indices()
@@ -50,14 +50,27 @@ def save(name, g, C, bc_face, rng, robin=False):
     if robin:
         w = 0.5 + rng.random(bc.robin_weight.shape[2])
         bc.robin_weight = np.einsum("ij,k->ijk", np.eye(g.dim), w)
+    if basis:
+        # a rotated (orthonormal) basis per sub-face (ExcludeBoundaries.basis_matrix, _fvutils.py:836-852, takes the
+        # (nd, nd, Nsf) array as it is); sub-faces of one face get different ones
+        nsub = bc.is_dir.shape[1]
+        Q = np.empty((g.dim, g.dim, nsub))
+        for k in range(nsub):
+            q, r = np.linalg.qr(rng.standard_normal((g.dim, g.dim)))
+            Q[:, :, k] = q * np.sign(np.diag(r))[None, :]
+        bc.basis = Q
     stress, bound_stress, hf_cell, hf_bound = pp.Mpsa("mechanics")._stress_discretization(
-        g, C, bc, eta=None, inverter="python")
+        g, C, bc, eta=None, inverter="python", hf_eta=hf_eta)
     store = {}
     for k, v in grid_to_raw(g).items():
         store["grid_" + k] = np.asarray(v)
     for k in ("is_dir", "is_neu", "is_rob"):
         store["bc_" + k] = np.asarray(getattr(bc, k), bool)
     store["bc_robin_weight"] = np.asarray(bc.robin_weight, float)
+    if basis:
+        store["bc_basis"] = np.asarray(bc.basis, float)
+    if hf_eta is not None:
+        store["hf_eta"] = np.float64(hf_eta)  # reconstruction_eta (mpsa.py:757-761)
     store["stiffness"] = np.ascontiguousarray(C.values)
     for k, m in zip(KEYS, (stress, bound_stress, hf_cell, hf_bound)):
         pack_csr("ref_" + k, m, store)
@@ -80,5 +93,27 @@ def main():
     save("mpsasub_tet3d_2x2x2", g, C, vec_bc(g, "roller"), rng)
 
 
+def main_basis():
+    """round 5: conditions per sub-face in a basis per sub-face"""
+    rng = np.random.default_rng(920)
+    g = perturb_interior(pp.StructuredTriangleGrid([3, 3], [1, 1]), rng, 0.08); nc = g.num_cells
+    C = pp.FourthOrderTensor(1 + rng.random(nc), 0.5 + rng.random(nc))
+    save("mpsasub_tri2d_3x3_basis_rob", g, C, vec_bc(g, "dir"), rng, robin=True, basis=True)
+    g = perturb_interior(pp.StructuredTetrahedralGrid([2, 2, 2], [1, 1, 1]), rng, 0.08); nc = g.num_cells
+    C = pp.FourthOrderTensor(1 + rng.random(nc), 0.5 + rng.random(nc))
+    save("mpsasub_tet3d_2x2x2_basis", g, C, vec_bc(g, "roller"), rng, basis=True)
+    # ... and displacement traces reconstructed away from the continuity points (reconstruction_eta) with
+    # conditions per sub-face
+    g = perturb_interior(pp.StructuredTriangleGrid([3, 3], [1, 1]), rng, 0.08); nc = g.num_cells
+    C = pp.FourthOrderTensor(1 + rng.random(nc), 0.5 + rng.random(nc))
+    save("mpsasub_tri2d_3x3_hfeta_basis", g, C, vec_bc(g, "dir"), rng, basis=True, hf_eta=0.0)
+    g = pp.CartGrid([3, 2, 2]); g.compute_geometry(); nc = g.num_cells
+    C = pp.FourthOrderTensor(1 + rng.random(nc), 0.5 + rng.random(nc))
+    save("mpsasub_cart3d_3x2x2_hfeta", g, C, vec_bc(g, "dir"), rng, hf_eta=0.25)
+
+
 if __name__ == "__main__":
-    main()
+    if "basis" in sys.argv[1:]:
+        main_basis()
+    else:
+        main()

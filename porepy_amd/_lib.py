@@ -36,13 +36,13 @@ EXPORTS = [
     "pfv_get_device_rhs", "pfv_sync", "pfv_get_stats", "pfv_time_kernel", "pfv_debug_copy",
     "pfv_spmv_device_rows", "pfv_copy_device_vector", "pfv_set_stream",
     "pfv_mpsa_set_params", "pfv_mpsa_discretize", "pfv_mpsa_assemble",
-    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_setup_sharded", "pfv_amg_apply_device", "pfv_csr_from_host", "pfv_csr_from_matrix", "pfv_csr_block_diag", "pfv_csr_matmul", "pfv_csr_axpby", "pfv_csr_transpose", "pfv_csr_bmat", "pfv_csr_scale", "pfv_csr_divide", "pfv_csr_spmv", "pfv_csr_spmv_device", "pfv_csr_info", "pfv_csr_get", "pfv_csr_set_system", "pfv_csr_free", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc", "pfv_mpsa_set_subface_bc",
+    "pfv_mpfa_discretize_faces", "pfv_set_system", "pfv_tpfa_discretize", "pfv_mpsa_discretize_faces", "pfv_set_preconditioner", "pfv_amg_setup", "pfv_amg_setup_sharded", "pfv_amg_apply_device", "pfv_csr_from_host", "pfv_csr_from_matrix", "pfv_csr_block_diag", "pfv_csr_matmul", "pfv_csr_axpby", "pfv_csr_transpose", "pfv_csr_bmat", "pfv_csr_scale", "pfv_csr_divide", "pfv_csr_spmv", "pfv_csr_spmv_device", "pfv_csr_info", "pfv_csr_get", "pfv_csr_set_system", "pfv_csr_free", "pfv_reset_stream", "pfv_mpsa_set_robin", "pfv_mpsa_set_basis", "pfv_mpfa_set_subface_bc", "pfv_mpsa_set_subface_bc", "pfv_mpsa_set_subface_basis",
     "pfv_biot_set_alphas", "pfv_biot_discretize", "pfv_biot_matrix_info", "pfv_biot_get_matrix",
     "pfv_set_vectors_on_device", "pfv_set_periodic", "pfv_biot_discretize_faces", "pfv_solve_sharded", "pfv_tpfa_transmissibility_ad",
     "pfv_get_matrix_rows", "pfv_active_size", "pfv_device_memory",
     "pfv_rccl_unique_id", "pfv_rccl_comm_create", "pfv_rccl_set_halo_plan", "pfv_rccl_hooks", "pfv_rccl_stats",
     "pfv_rccl_last_error", "pfv_rccl_comm_destroy", "pfv_mpfa_ad_flux_system", "pfv_host_alloc", "pfv_host_free",
-    "pfv_mpsa_set_subface_eta", "pfv_mpsa_set_reconstruction_eta", "pfv_get_stats_n", "pfv_set_block_preconditioner",
+    "pfv_mpsa_set_subface_eta", "pfv_mpsa_set_reconstruction_eta", "pfv_mpsa_set_reconstruction_eta_subface", "pfv_get_stats_n", "pfv_set_block_preconditioner",
     "pfv_mpfa_set_permeability",
 ]
 
@@ -136,12 +136,16 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.pfv_mpsa_set_basis.restype = C.c_int
     lib.pfv_mpsa_set_subface_bc.argtypes = [_h, _up, _up, _up, _dp]
     lib.pfv_mpsa_set_subface_bc.restype = C.c_int
+    lib.pfv_mpsa_set_subface_basis.argtypes = [_h, _dp]
+    lib.pfv_mpsa_set_subface_basis.restype = C.c_int
     lib.pfv_mpsa_set_robin.argtypes = [_h, _up, _dp]
     lib.pfv_mpsa_set_robin.restype = C.c_int
     lib.pfv_mpsa_set_subface_eta.argtypes = [_h, _dp]
     lib.pfv_mpsa_set_subface_eta.restype = C.c_int
     lib.pfv_mpsa_set_reconstruction_eta.argtypes = [_h, C.c_int, C.c_double]
     lib.pfv_mpsa_set_reconstruction_eta.restype = C.c_int
+    lib.pfv_mpsa_set_reconstruction_eta_subface.argtypes = [_h, _dp]
+    lib.pfv_mpsa_set_reconstruction_eta_subface.restype = C.c_int
     lib.pfv_reset_stream.argtypes = [_h]
     lib.pfv_reset_stream.restype = C.c_int
     lib.pfv_amg_setup.argtypes = [_h, C.c_int64]
@@ -652,13 +656,23 @@ class Context:
 
     def mpsa_set_reconstruction_eta(self, hf_eta):
         """``reconstruction_eta`` (mpsa.py:185, 757-761): where the displacement traces are reconstructed; None = at
-        the continuity points.  After ``mpsa_set_params``."""
+        the continuity points; an array = one value per sub-face (sorted CSC order of face_nodes), used as given also
+        on the boundary.  After ``mpsa_set_params``."""
+        if hf_eta is not None and np.ndim(hf_eta) > 0 and np.size(hf_eta) != 1:
+            e = _f64(np.asarray(hf_eta, dtype=float).ravel())
+            if e.size != self.nsf:
+                raise ValueError("reconstruction_eta per sub-face must have Nsf entries")
+            self._check(self.lib.pfv_mpsa_set_reconstruction_eta_subface(self._h, _ptr(e, _dp)))
+            return
+        if hf_eta is not None:
+            hf_eta = float(np.asarray(hf_eta).ravel()[0])
         self._check(self.lib.pfv_mpsa_set_reconstruction_eta(self._h, 0 if hf_eta is None else 1,
                                                              0.0 if hf_eta is None else float(hf_eta)))
 
-    def mpsa_set_subface_bc(self, is_dir_sub, is_neu_sub, is_rob_sub=None, robin_weight_sub=None):
+    def mpsa_set_subface_bc(self, is_dir_sub, is_neu_sub, is_rob_sub=None, robin_weight_sub=None, basis_sub=None):
         """Conditions per sub-face (include/porefv.h: pfv_mpsa_set_subface_bc): boolean (nd, Nsf) arrays in the
-        order of the sorted face_nodes CSC arrays, optional Robin weights (nd, nd, Nsf).  After mpsa_set_params."""
+        order of the sorted face_nodes CSC arrays, optional Robin weights (nd, nd, Nsf) and basis (nd, nd, Nsf:
+        pfv_mpsa_set_subface_basis).  After mpsa_set_params."""
         is_dir, is_neu = np.asarray(is_dir_sub, bool), np.asarray(is_neu_sub, bool)
         if is_dir.shape != (self.nd, self.nsf) or is_neu.shape != (self.nd, self.nsf):
             raise ValueError("is_dir / is_neu per sub-face must have shape (nd, Nsf)")
@@ -677,6 +691,12 @@ class Context:
                     raise ValueError("robin_weight per sub-face must have shape (nd, nd, Nsf)")
         self._check(self.lib.pfv_mpsa_set_subface_bc(self._h, _ptr(dbits, _up), _ptr(nbits, _up), _ptr(rbits, _up),
                                                      _ptr(W, _dp)))
+        if basis_sub is not None:
+            B = _f64(basis_sub)
+            if B.shape != (self.nd, self.nd, self.nsf):
+                raise ValueError("basis per sub-face must have shape (nd, nd, Nsf)")
+            if not np.array_equal(B, np.broadcast_to(np.eye(self.nd)[:, :, None], B.shape)):
+                self._check(self.lib.pfv_mpsa_set_subface_basis(self._h, _ptr(B, _dp)))
 
     # ---- Biot coupling terms ------------------------------------------------------------
     def biot_set_alphas(self, alphas):

@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _lib
 from .grid import grid_to_raw
-from .mpfa import determine_eta, estimate_device_bytes, partition_cells, plan_subproblems
+from .mpfa import determine_eta, estimate_device_bytes, note_ignored_parameters, partition_cells, plan_subproblems
 from .partial import active_indices
 from .mpsa import Mpsa
 from .mpsa import _KEYS as _MECH_KEYS
@@ -67,9 +67,12 @@ class Biot(Mpsa):
             eta = determine_eta(sd)
         elif np.asarray(eta).size != 1:
             raise NotImplementedError("continuity points per sub-face are not covered for the Biot coupling terms")
-        hf_eta = pd.get("reconstruction_eta", None)
-        if hf_eta is not None and (np.asarray(hf_eta).size != 1 or float(hf_eta) != float(eta)):
-            raise NotImplementedError("reconstruction_eta different from mpsa_eta is not covered for the Biot coupling terms")
+        # the reference's Biot reconstructs the displacement traces at the continuity points whatever
+        # ``reconstruction_eta`` says (biot.py:803-805 calls _reconstruct_displacement with eta; the key is never read):
+        # the same here, with a note
+        note_ignored_parameters(pd, self.keyword, {
+            "reconstruction_eta": "Biot reconstructs the displacement traces at the continuity points of `mpsa_eta`, as "
+                                  "the reference's Biot does (it never reads the key)"})
         self._split.pop(id(sd), None)
         ent = self._contexts.get(id(sd))
         if alphas and not (partial or update) and not (

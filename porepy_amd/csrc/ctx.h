@@ -191,10 +191,14 @@ struct pfv_ctx_impl {
   bool have_mpsa_eta_sub = false;  // continuity points per sub-face (pfv_mpsa_set_subface_eta)
   bool mpsa_hf_on = false;         // reconstruction_eta given (pfv_mpsa_set_reconstruction_eta)
   double mpsa_hf_eta = 0.0;
+  Buf<double> mpsa_hf_eta_sub;     // [Nsf] reconstruction_eta per sub-face (used as given, also on the boundary)
+  bool have_mpsa_hf_eta_sub = false;
   Buf<double> Et2, Etb2;           // traces reconstructed at the hf_eta points (layout of Et / Etb)
   Buf<double> mpsa_eta_sub;
   Buf<double> mpsa_basis;            // [nd*nd][Nf] boundary basis (BoundaryConditionVectorial.basis)
   bool have_mpsa_basis = false;
+  Buf<double> mpsa_basis_sub;        // [nd*nd][Nsf] the same per sub-face (conditions per sub-face, mpsa.py:712-720)
+  bool have_mpsa_basis_sub = false;
   Buf<char> mpsa_scratch;            // global-memory work space of interaction regions too large for the LDS
   Buf<long long> mpsa_clk;           // timing lab (PFV_MPSA_CLOCK): s_memtime stamps of one workgroup
   // conditions per sub-face (mpsa.py:712-720): flags / weights per sub-face replace the per-face ones, stress and

@@ -786,7 +786,9 @@ pfv_status pfv_mpsa_set_params(pfv_ctx* h, const double* stiffness_99n, const do
     h->have_mpsa_robin = false;
     h->have_mpsa_eta_sub = false;
     h->mpsa_hf_on = false;
+    h->have_mpsa_hf_eta_sub = false;
     h->have_mpsa_basis = false;
+    h->have_mpsa_basis_sub = false;
     h->mpsa_subface_bc = false;
     h->mpsa_eta = eta;
     h->have_mpsa_params = true;
@@ -835,6 +837,29 @@ pfv_status pfv_mpsa_set_reconstruction_eta(pfv_ctx* h, int on, double hf_eta) {
     require(!on || (hf_eta >= 0.0 && hf_eta < 1.0), "reconstruction_eta must lie in [0, 1)");
     h->mpsa_hf_on = on != 0;
     h->mpsa_hf_eta = hf_eta;
+    h->have_mpsa_hf_eta_sub = false;
+    h->have_mpsa_numeric = false;
+    h->have_mech_system = false;
+  });
+}
+
+pfv_status pfv_mpsa_set_reconstruction_eta_subface(pfv_ctx* h, const double* hf_eta_subface) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_mpsa_params, "pfv_mpsa_set_params first");
+    h->have_mpsa_hf_eta_sub = false;
+    h->mpsa_hf_on = hf_eta_subface != nullptr;
+    if (hf_eta_subface) {
+      if (!h->have_topology) {  // the sub-face count is known from the topology
+        pfv::build_topology(*h);
+        pfv::build_symbolic(*h);
+        h->tpfa_mode = false;
+        h->have_mpsa_symbolic = false;
+        h->have_sub_symbolic = h->have_mpsa_sub_symbolic = false;
+        h->have_numeric = h->have_system = false;
+      }
+      upload(h->mpsa_hf_eta_sub, hf_eta_subface, (size_t)h->nsf, h->stream);
+      h->have_mpsa_hf_eta_sub = true;
+    }
     h->have_mpsa_numeric = false;
     h->have_mech_system = false;
   });
@@ -858,10 +883,11 @@ pfv_status pfv_mpsa_set_subface_bc(pfv_ctx* h, const uint8_t* bc_dir_bits_sub, c
   return guarded(h, [&] {
     require(h->have_grid && h->have_mpsa_params, "pfv_mpsa_set_params first");
     h->mpsa_subface_bc = false;
+    h->have_mpsa_basis_sub = false;
     h->have_mpsa_numeric = h->have_mech_system = false;
     if (!bc_dir_bits_sub) return;  // back to conditions per face
     require(bc_neu_bits_sub != nullptr, "null parameter array");
-    require(!h->have_mpsa_basis, "conditions per sub-face in a face-wise basis are not covered");
+    require(!h->have_mpsa_basis, "conditions per sub-face take their basis per sub-face: pfv_mpsa_set_subface_basis");
     require(h->biot_nalpha == 0, "conditions per sub-face with Biot coupling terms are not covered");
     auto s = h->stream;
     if (!h->have_topology) {  // the sub-face count is known from the topology
@@ -888,6 +914,19 @@ pfv_status pfv_mpsa_set_subface_bc(pfv_ctx* h, const uint8_t* bc_dir_bits_sub, c
       }
     }
     h->mpsa_subface_bc = true;
+  });
+}
+
+pfv_status pfv_mpsa_set_subface_basis(pfv_ctx* h, const double* basis_dds) {
+  return guarded(h, [&] {
+    require(h->have_grid && h->have_mpsa_params && h->mpsa_subface_bc, "pfv_mpsa_set_subface_bc first");
+    h->have_mpsa_basis_sub = false;
+    if (basis_dds) {
+      upload(h->mpsa_basis_sub, basis_dds, (size_t)h->nd * h->nd * (size_t)h->nsf, h->stream);
+      h->have_mpsa_basis_sub = true;
+    }
+    h->have_mpsa_numeric = false;
+    h->have_mech_system = false;
   });
 }
 

@@ -84,8 +84,13 @@ class Mpsa:
             eta = 0.0
         hf_eta = pd.get("reconstruction_eta", None)
         if hf_eta is not None and np.asarray(hf_eta).size != 1:
-            raise NotImplementedError("reconstruction_eta per sub-face is not covered")
-        if hf_eta is not None and eta_sub is None and float(hf_eta) == float(eta):
+            # one reconstruction point per sub-face (compute_dist_face_cell with an array, _fvutils.py:222-277), in the
+            # storage order of the caller's face_nodes
+            hf_eta = np.asarray(hf_eta, dtype=float).ravel()
+            if hf_eta.size != nsub:
+                raise ValueError("size of eta must either be 1 or number of subfaces")
+            hf_eta = hf_eta[subface_order(sd.face_nodes)]
+        elif hf_eta is not None and eta_sub is None and float(hf_eta) == float(eta):
             hf_eta = None  # the continuity points themselves
         note_ignored_parameters(pd, self.keyword, {
             "inverter": "the local systems are inverted by the device kernel (register Gauss-Jordan); the reference's "
@@ -112,27 +117,27 @@ class Mpsa:
             # the device numbers sub-faces by the sorted CSC arrays
             if partial or update:
                 raise NotImplementedError("partial discretization with conditions per sub-face is not covered")
-            if basis is not None and not np.array_equal(
-                    np.asarray(basis), np.tile(np.eye(sd.dim)[:, :, None], (1, 1, nsub))):
-                raise NotImplementedError("conditions per sub-face in a face-wise basis are not covered")
             order = subface_order(sd.face_nodes)
+            if basis is not None and np.asarray(basis).shape != (sd.dim, sd.dim, nsub):
+                raise ValueError("the basis of conditions per sub-face must have one entry per sub-face")
             nd, nf = sd.dim, sd.num_faces
             ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, np.zeros((nd, nf), bool), np.ones((nd, nf), bool),
                                 float(eta))  # per-face placeholders; the sub-face arrays take over
             rob_sub = None if is_rob is None else np.asarray(is_rob, bool)[:, order]
             rw = getattr(bnd, "robin_weight", None)
             ctx.mpsa_set_subface_bc(np.asarray(bnd.is_dir, bool)[:, order], np.asarray(bnd.is_neu, bool)[:, order],
-                                    rob_sub, None if (rob_sub is None or rw is None) else np.asarray(rw, float)[:, :, order])
+                                    rob_sub, None if (rob_sub is None or rw is None) else np.asarray(rw, float)[:, :, order],
+                                    basis_sub=None if basis is None else np.asarray(basis, float)[:, :, order])
         else:
             ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta),
                                 is_rob=is_rob,
                                 robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None,
                                 basis=basis)
         ctx.mpsa_set_subface_eta(eta_sub)  # (None: the scalar eta of mpsa_set_params)
-        if hf_eta is not None and (subface or partial or update):
-            raise NotImplementedError("reconstruction_eta with conditions per sub-face or partial updates is not covered")
+        if hf_eta is not None and (partial or update):
+            raise NotImplementedError("reconstruction_eta with partial updates is not covered")
         # displacement traces reconstructed at x_f + hf_eta (x_v - x_f) (mpsa.py:185, 757-761, 1187-1266)
-        ctx.mpsa_set_reconstruction_eta(None if hf_eta is None else float(hf_eta))
+        ctx.mpsa_set_reconstruction_eta(hf_eta)
         rows = None
         try:
             if partial:

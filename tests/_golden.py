@@ -46,6 +46,9 @@ class MpsaSubfaceCase:
         self.grid["name"] = str(self.grid["name"])
         self.bc = {"is_dir": z["bc_is_dir"], "is_neu": z["bc_is_neu"], "is_rob": z["bc_is_rob"],
                    "robin_weight": z["bc_robin_weight"]}
+        if "bc_basis" in z.files:  # (round 5: a basis per sub-face)
+            self.bc["basis"] = z["bc_basis"]
+        self.hf_eta = float(z["hf_eta"]) if "hf_eta" in z.files else None  # reconstruction_eta
         self.stiffness = z["stiffness"]
         self.ref = {}
         for k in MPSA_KEYS:
@@ -75,6 +78,8 @@ class MpsaCase:
         self.eta = None if np.isnan(eta) else eta
         self.eta_sub = z["eta_sub"] if "eta_sub" in z.files else None  # continuity points per sub-face (sorted CSC order)
         self.hf_eta = float(z["hf_eta"]) if "hf_eta" in z.files else None  # reconstruction_eta
+        if "hf_eta_sub" in z.files:  # ... one value per sub-face (sorted CSC order)
+            self.hf_eta = z["hf_eta_sub"]
         self.ref = {}
         for k in MPSA_KEYS + ("A",):
             if f"ref_{k}_indptr" in z.files:

@@ -442,14 +442,17 @@ def check_mpsa_subface_case(lib, name: str, scramble: bool = False):
 
     c = MpsaSubfaceCase(name)
     nd = c.grid["dim"]
-    ora = so.discretize(c.grid, c.stiffness, c.bc)
+    ora = so.discretize(c.grid, c.stiffness, c.bc, hf_eta=c.hf_eta)
     if not scramble:
         ctx = pa.Context(0, lib)
         ctx.set_grid(c.grid)
         nf = c.grid["face_centers"].shape[1]
         ctx.mpsa_set_params(c.stiffness, c.grid["cell_volumes"], np.zeros((nd, nf), bool), np.ones((nd, nf), bool),
                             mo.default_eta(c.grid["name"]))
-        ctx.mpsa_set_subface_bc(c.bc["is_dir"], c.bc["is_neu"], c.bc["is_rob"], c.bc["robin_weight"])
+        ctx.mpsa_set_subface_bc(c.bc["is_dir"], c.bc["is_neu"], c.bc["is_rob"], c.bc["robin_weight"],
+                                basis_sub=c.bc.get("basis"))
+        if c.hf_eta is not None:
+            ctx.mpsa_set_reconstruction_eta(c.hf_eta)
         ctx.mpsa_discretize()
         for k in MPSA_KEYS:
             M = ctx.matrix(MPSA_WHICH[k])
@@ -484,13 +487,17 @@ def check_mpsa_subface_case(lib, name: str, scramble: bool = False):
     bc = pa.BoundaryConditionVectorial(g)
     bc.is_dir, bc.is_neu, bc.is_rob = c.bc["is_dir"][:, perm], c.bc["is_neu"][:, perm], c.bc["is_rob"][:, perm]
     bc.robin_weight = c.bc["robin_weight"][:, :, perm]
-    bc.basis = np.tile(np.eye(nd)[:, :, None], (1, 1, perm.size))
+    bc.basis = (np.tile(np.eye(nd)[:, :, None], (1, 1, perm.size)) if c.bc.get("basis") is None
+                else c.bc["basis"][:, :, perm])
     bc.num_faces = perm.size
     C = pa.FourthOrderTensor.from_values(c.stiffness) if hasattr(pa.FourthOrderTensor, "from_values") else None
     if C is None:
         C = pa.FourthOrderTensor(np.ones(g.num_cells), np.ones(g.num_cells))
         C.values = c.stiffness
-    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc})
+    par = {"fourth_order_tensor": C, "bc": bc}
+    if c.hf_eta is not None:
+        par["reconstruction_eta"] = c.hf_eta
+    data = pa.initialize_data({}, "mechanics", par)
     pa.Mpsa("mechanics", library=lib).discretize(g, data)
     md = data[pa.DISCRETIZATION_MATRICES]["mechanics"]
     blk = (nd * perm[:, None] + np.arange(nd)[None, :]).ravel()  # caller block -> sorted block
@@ -761,6 +768,15 @@ def check_biot_case(lib, name: str):
             assert np.array_equal(M.indptr, ora[k][key].indptr) and np.array_equal(M.indices, ora[k][key].indices), (name, k, key)
             assert rel_max_err(M, ora[k][key]) < TOL, (name, k, key)
             assert rel_max_err(M, c.ref[k][key]) < TOL, (name, k, key)
+    # ``reconstruction_eta`` is never read by the reference's Biot (biot.py:803-805 reconstructs at eta): the same matrices
+    data2 = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "scalar_vector_mappings": maps,
+                                                "reconstruction_eta": 0.05})
+    pa.Biot("mechanics", library=lib).discretize(g, data2)
+    md2 = data2[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    for k in ("bound_displacement_cell", "bound_displacement_face"):
+        assert abs(md2[k] - md[k]).max() == 0.0, (name, k)
+    for key in c.alphas:
+        assert abs(md2["bound_displacement_pressure"][key] - md["bound_displacement_pressure"][key]).max() == 0.0
 
 
 def check_subface_case(lib, name: str, scramble: bool = False):

@@ -123,7 +123,9 @@ def test_config_c3_all_four_matrices_on_patches(lib):
     assert max(out["worst_rel_err_vs_reference"].values()) < 1e-10
 
 
-@pytest.mark.parametrize("name", ["mpsasub_cart2d_4x3", "mpsasub_tri2d_3x3_rob", "mpsasub_tet3d_2x2x2"])
+@pytest.mark.parametrize("name", ["mpsasub_cart2d_4x3", "mpsasub_tri2d_3x3_rob", "mpsasub_tet3d_2x2x2",
+                                  "mpsasub_tri2d_3x3_basis_rob", "mpsasub_tet3d_2x2x2_basis",
+                                  "mpsasub_tri2d_3x3_hfeta_basis", "mpsasub_cart3d_3x2x2_hfeta"])
 @pytest.mark.parametrize("scramble", [False, True])
 def test_boundary_conditions_per_subface(lib, name, scramble):
     P.check_mpsa_subface_case(lib, name, scramble)

@@ -228,6 +228,37 @@ def test_newton_iteration_with_device_resident_jacobian(lib):
     assert np.linalg.norm(r) < 1e-9 * norms[0]
 
 
+def test_mpsa_reconstruction_eta_per_subface_through_the_host_mirror(lib):
+    """``reconstruction_eta`` as an array (one value per sub-face, _fvutils.py:222-277): ``pa.Mpsa`` against the matrices
+    the reference produced (fixture of oracle/gen_golden_mpsa_hfeta_sub.py), with the caller's face_nodes stored
+    unsorted -- the array follows the caller's sub-face numbering, the device's follows the sorted CSC arrays."""
+    import scipy.sparse as sps
+
+    from tests._golden import MPSA_KEYS, MpsaCase, rel_max_err
+
+    c = MpsaCase("mpsa_hfetasub_tri2d_3x3")
+    g = pa.grid_from_raw(c.grid)
+    fn = sps.csc_matrix(g.face_nodes)
+    perm = np.arange(fn.indices.size)
+    for f in range(fn.shape[1]):
+        a, b = fn.indptr[f], fn.indptr[f + 1]
+        perm[a:b] = perm[a:b][::-1]
+    g.face_nodes = sps.csc_matrix((fn.data[perm], fn.indices[perm], fn.indptr), shape=fn.shape)
+    bc = pa.BoundaryConditionVectorial(g)
+    bc.is_dir, bc.is_neu = c.bc["is_dir"], c.bc["is_neu"]
+    C = pa.FourthOrderTensor(np.ones(g.num_cells), np.ones(g.num_cells))
+    C.values = c.stiffness
+    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "mpsa_eta": 1.0 / 3.0,
+                                               "reconstruction_eta": c.hf_eta[perm]})
+    pa.Mpsa("mechanics", library=lib).discretize(g, data)
+    md = data[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    for k in MPSA_KEYS:
+        assert rel_max_err(md[k], c.ref[k]) < 1e-10, k
+    with pytest.raises(ValueError, match="size of eta"):
+        bad = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "reconstruction_eta": np.ones(5)})
+        pa.Mpsa("mechanics", library=lib).discretize(g, bad)
+
+
 def test_mpsa_reconstruction_eta(lib):
     """``reconstruction_eta`` (mpsa.py:185, 757-761): the displacement traces are reconstructed at another point than
     the continuity point -- the trace matrices change, stress / bound_stress do not; against the oracle (whose

@@ -34,7 +34,7 @@ def test_mpsa_oracle_with_conditions_per_subface(name):
     """mpsa.py:712-720, 752-754, 780-781, 1127-1138: sub-face rows of stress / bound_stress, sub-face columns of
     the boundary matrices, Neumann data integrated over the sub-face."""
     c = MpsaSubfaceCase(name)
-    out = so.discretize(c.grid, c.stiffness, c.bc)
+    out = so.discretize(c.grid, c.stiffness, c.bc, hf_eta=c.hf_eta)
     for k in MPSA_KEYS:
         assert out[k].shape == c.ref[k].shape, (name, k)
         assert rel_max_err(out[k], c.ref[k]) < TOL, (name, k)
