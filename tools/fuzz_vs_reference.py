@@ -433,7 +433,8 @@ def case_contrast(lib, seed):
     nd, nc, nf = g.dim, g.num_cells, g.num_faces
     h = pa.grid_from_raw(grid_to_raw(g))
     bf = g.get_all_boundary_faces()
-    decades = rng.uniform(10.0, 15.0)
+    lo, hi = (float(x) for x in os.environ.get("PFV_FUZZ_DECADES", "10,15").split(","))  # (default: the range VERDICT r4 named)
+    decades = rng.uniform(lo, hi)
     s = 10.0 ** (decades * (rng.random(nc) - 0.5))
     if rng.random() < 0.5:  # two-valued field: the sharpest jumps
         s = np.where(rng.random(nc) < 0.5, 10.0 ** (-decades / 2), 10.0 ** (decades / 2))
@@ -466,6 +467,36 @@ def case_contrast(lib, seed):
     elif ref_ok:
         r, o = rdata[pp.DISCRETIZATION_MATRICES]["flow"], hdata[pa.DISCRETIZATION_MATRICES]["flow"]
         out.append((f"flow, contrast 1e{decades:.1f}", max(rel(o[k], r[k]) for k in FLOW)))
+    # ---- the same for the mechanics: Lame parameters spanning the contrast
+    vb = pp.BoundaryConditionVectorial(g)
+    for a in range(nd):
+        tdir = rng.random(bf.size) < 0.6
+        vb.is_dir[a, bf[tdir]], vb.is_neu[a, bf[tdir]] = True, False
+    vb.is_dir[:, bf[:2]], vb.is_neu[:, bf[:2]] = True, False
+    mu, lam = s * (0.5 + rng.random(nc)), s * (0.5 + rng.random(nc))
+    rdata = pp.initialize_data({}, "mechanics", {"fourth_order_tensor": pp.FourthOrderTensor(mu, lam), "bc": vb,
+                                                 "inverter": "python"})
+    hv = pa.BoundaryConditionVectorial(h)
+    hv.is_dir, hv.is_neu = vb.is_dir.copy(), vb.is_neu.copy()
+    hdata = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": pa.FourthOrderTensor(mu, lam), "bc": hv})
+    try:
+        pp.Mpsa("mechanics").discretize(g, rdata)
+        ref_ok = True
+    except Exception as e:
+        ref_ok = False
+        out.append(f"mechanics, contrast 1e{decades:.1f}: reference raised {type(e).__name__}")
+    try:
+        pa.Mpsa("mechanics", library=lib).discretize(h, hdata)
+        ours_ok = True
+    except ValueError:
+        ours_ok = False
+    if ref_ok != ours_ok:
+        out.append(f"mechanics, contrast 1e{decades:.1f}: VERDICTS DIFFER (reference {'returned' if ref_ok else 'raised'}, "
+                   f"device {'returned' if ours_ok else 'raised'})")
+        out.append(("verdict (mechanics)", 1.0))
+    elif ref_ok:
+        r, o = rdata[pp.DISCRETIZATION_MATRICES]["mechanics"], hdata[pa.DISCRETIZATION_MATRICES]["mechanics"]
+        out.append((f"mechanics, contrast 1e{decades:.1f}", max(rel(o[k], r[k]) for k in MECH)))
     return kind, nc, out
 
 
