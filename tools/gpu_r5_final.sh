@@ -39,6 +39,19 @@ if [ -n "$ENVF" ]; then
   (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH="$ENVF:$R" timeout 600 python $R/tools/fuzz_vs_reference.py 40 918273 > $R/$O/fuzz_device_vs_reference.log 2>&1; tail -2 $R/$O/fuzz_device_vs_reference.log)
   (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH="$ENVF:$R" timeout 600 python $R/tools/fuzz_vs_reference.py 30 555111 special > $R/$O/fuzz_device_vs_reference_special.log 2>&1; tail -2 $R/$O/fuzz_device_vs_reference_special.log)
   (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH="$ENVF:$R" timeout 600 python $R/tools/fuzz_vs_reference.py 40 7000 contrast > $R/$O/fuzz_device_vs_reference_contrast.log 2>&1; tail -2 $R/$O/fuzz_device_vs_reference_contrast.log)
+  (cd /tmp && PFV_FUZZ_DECADES=2,6 PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH="$ENVF:$R" timeout 600 python $R/tools/fuzz_vs_reference.py 30 7100 contrast > $R/$O/fuzz_device_vs_reference_contrast_1e2_1e6.log 2>&1; tail -2 $R/$O/fuzz_device_vs_reference_contrast_1e2_1e6.log)
 fi
 stamp fuzz
+# the command the driver runs at round end
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+python - "$O" <<'PY'
+import json, sys
+o = sys.argv[1]
+try:
+    d = json.loads([l for l in open(f"{o}/bench_driver_cmd.json") if l.startswith("{")][-1])
+    print(f"driver cmd: ms/step {d['ms_per_step']:.2f} cold {d['ms_per_step_cold']:.2f} its {d['config']['iterations']} asm frac {d['assembly']['frac_of_hbm_peak']:.3f} roofline {d['roofline']['frac']:.3f}")
+except Exception as e:
+    print("driver-cmd bench FAILED", e, open(f"{o}/bench_driver_cmd.err").read()[-1500:])
+PY
+stamp bench20
 cat $O/timeline.log
