@@ -22,7 +22,7 @@ from . import _lib
 from .lazy import LazyCsr
 from .grid import grid_to_raw
 from .partial import active_indices
-from .periodic import merge_periodic
+from .periodic import merge_periodic, merged_subface_order
 from .params import DISCRETIZATION_MATRICES, PARAMETERS, bc_flags
 
 _KEYS = (
@@ -449,6 +449,12 @@ class Mpfa:
         partial = any(v is not None for v in spec)
         update = bool(pd.get("update_discretization", False))
         nsub = sps_nnz(sd.face_nodes)
+        if hasattr(sd, "periodic_face_map"):
+            # the right sub-faces share the numbers of the left ones (SubcellTopology.num_subfno_unique, _fvutils.py:91-160)
+            import scipy.sparse as sps
+
+            nnf = np.diff(sps.csc_matrix(sd.face_nodes).indptr)
+            nsub -= int(nnf[np.asarray(sd.periodic_face_map)[1]].sum())
         subface = np.asarray(bnd.is_dir).size == nsub and nsub != sd.num_faces
         if not subface and np.asarray(bnd.is_dir).size != sd.num_faces:
             raise ValueError("boundary condition arrays must have one entry per face or per sub-face")
@@ -485,8 +491,8 @@ class Mpfa:
         ctx = self.context(sd)
         T = self._plane.get(id(sd))
         merge = self._periodic.get(id(sd))
-        if merge is not None and (partial or update or subface):
-            raise NotImplementedError("periodic faces: full discretization with conditions per face only")
+        if merge is not None and (partial or update):
+            raise NotImplementedError("periodic faces: full discretization only")
         kval = np.asarray(k.values, dtype=float)
         if T is not None:
             # rotate the tensor into the plane (mpfa.py:748-754)
@@ -498,7 +504,7 @@ class Mpfa:
         if subface:
             # conditions per sub-face follow the storage order of the caller's face_nodes; the device
             # numbers sub-faces by the sorted CSC arrays (mpfa.py:761-768, _fvutils.py:78-90)
-            order = subface_order(sd.face_nodes)
+            order = subface_order(sd.face_nodes) if merge is None else merged_subface_order(sd.face_nodes, merge)
             flags_sub = bc_flags(bnd)[order]
             robin_sub = np.asarray(bnd.robin_weight, dtype=float)[order]
             bnd = _FaceBC(sd.num_faces)  # per-face placeholders; the sub-face arrays take over below
@@ -559,7 +565,8 @@ class Mpfa:
                     md[name] = LazyCsr(ctx, which)
                 continue
             new = ctx.matrix(which, rows=rows)
-            if merge is not None:
+            if merge is not None and (order is None or "vector_source" in name):
+                # (with conditions per sub-face only the vector-source matrices have face rows: mpfa.py:1117-1147)
                 new = merge.copy_rows(new, trace=name.startswith("bound_pressure"))
             if lift is not None and "vector_source" in name:
                 new = (new @ lift).tocsr()

@@ -29,7 +29,8 @@ import scipy.sparse as sps
 class PeriodicMerge:
     """Result of :func:`merge_periodic`."""
 
-    def __init__(self, raw, native, shift, left, right):
+    def __init__(self, raw, native, shift, left, right, label=None):
+        self.label = label      # (Nn,) node renaming (right nodes carry the labels of the left ones)
         self.raw = raw          # merged raw grid (see grid.grid_to_raw)
         self.native = native    # (Nf,) int32: cell that sees a merged face in place, -1 elsewhere
         self.shift = shift      # (3, Nf): x_f(left) - x_f(right) at the left faces
@@ -53,6 +54,23 @@ class PeriodicMerge:
         out = out.tocsr()
         out.sort_indices()
         return out
+
+
+def merged_subface_order(face_nodes, merge: PeriodicMerge) -> np.ndarray:
+    """Conditions per sub-face on a grid with periodic faces: the reference numbers the merged sub-faces by their
+    position in the caller's face_nodes arrays, the right sub-faces taking the numbers of the left ones and the gaps
+    closed (SubcellTopology, numerics/fv/_fvutils.py:82-160); the device numbers them by the sorted CSC arrays of the
+    merged grid (right faces emptied, nodes renamed).  order[d] = the caller's number of device sub-face d."""
+    fn = sps.csc_matrix(face_nodes)
+    nf = fn.shape[1]
+    nnf = np.diff(fn.indptr)
+    keep_face = np.ones(nf, dtype=bool)
+    keep_face[merge.right] = False
+    keep = np.repeat(keep_face, nnf)                      # caller positions that survive
+    face = np.repeat(np.arange(nf), nnf)[keep]
+    lbl = merge.label[fn.indices[keep]]
+    caller = np.arange(int(keep.sum()))                   # compact numbers, in the caller's storage order
+    return caller[np.lexsort((lbl, face))]
 
 
 def merge_periodic(raw: dict, periodic_face_map) -> PeriodicMerge:
@@ -130,4 +148,4 @@ def merge_periodic(raw: dict, periodic_face_map) -> PeriodicMerge:
     shift[:, left] = fc[:, left] - fc[:, right]
     out["periodic_native"] = native
     out["periodic_shift"] = shift
-    return PeriodicMerge(out, native, shift, left, right)
+    return PeriodicMerge(out, native, shift, left, right, label=label)

@@ -854,6 +854,50 @@ def device_resident_vectors(lib, g, to_device=None, from_device=None):
     assert np.array_equal(x2, x_host)
 
 
+def check_periodic_subface_case(lib, name: str, scramble: bool = False):
+    """Conditions per sub-face on a grid WITH periodic faces (round 5; _fvutils.py:91-160 numbers the merged sub-faces,
+    mpfa.py:761-768, 900-917, 1117-1147): the six matrices against what the reference's ``_flux_discretization``
+    produced (oracle/gen_golden_periodic_subface.py).  scramble = True stores the caller's face_nodes with the node
+    order inside every column reversed: conditions and results then follow that numbering of the merged sub-faces."""
+    import scipy.sparse as sps
+
+    from tests._golden import SubfaceCase
+
+    c = SubfaceCase(name)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    pmap = z["periodic_face_map"]
+    g = pa.grid_from_raw(c.grid)
+    g.set_periodic_map(pmap)
+    fn = g.face_nodes.tocsc()
+    ptr = fn.indptr
+    nnf = np.diff(ptr)
+    keep = np.ones(g.num_faces, bool)
+    keep[pmap[1]] = False
+    nsub_u = int(nnf[keep].sum())
+    assert c.bc["is_dir"].size == nsub_u
+    perm_u = np.arange(nsub_u)  # caller's merged number -> the fixture's merged number
+    if scramble:
+        perm = np.concatenate([np.arange(ptr[f], ptr[f + 1])[::-1] for f in range(g.num_faces)])
+        g.face_nodes = sps.csc_matrix((fn.data[perm], fn.indices[perm], ptr.copy()), shape=fn.shape)
+        # merged numbers = ranks among the positions of the kept faces, in storage order
+        off = np.concatenate([[0], np.cumsum(np.where(keep, nnf, 0))])
+        perm_u = np.concatenate([np.arange(off[f], off[f + 1])[::-1] for f in range(g.num_faces)]).astype(int)
+    bc = _RawBC({k: (np.asarray(v)[perm_u] if np.asarray(v).size == nsub_u else v) for k, v in c.bc.items()})
+    K = type("K", (), {"values": c.perm})()
+    data = pa.initialize_data({}, "flow", {"second_order_tensor": K, "bc": bc})
+    pa.Mpfa("flow", library=lib).discretize(g, data)
+    inv = np.argsort(perm_u)  # fixture's merged number -> caller's
+    for k in ALL_KEYS:
+        M = data[pa.DISCRETIZATION_MATRICES]["flow"][k]
+        ref = c.ref[k]
+        if scramble and "vector_source" not in k:
+            coo = ref.tocoo()
+            cols = inv[coo.col] if k in ("bound_flux", "bound_pressure_face") else coo.col
+            ref = sps.csr_matrix((coo.data, (inv[coo.row], cols)), shape=ref.shape)
+        assert M.shape == ref.shape, (name, k, M.shape, ref.shape)
+        assert rel_max_err(M, ref) < TOL, (name, k, scramble)
+
+
 def check_periodic_case(lib, name: str, scheme: str = "mpfa"):
     """Grids with periodic faces (Grid.set_periodic_map): all six matrices, A and b of Mpfa / Tpfa
     against the reference (_fvutils.py:91-137, mpfa.py:900-917, tpfa.py:114-262), and the solve."""

@@ -331,6 +331,12 @@ def test_boundary_conditions_per_subface(lib, name, scramble):
     P.check_subface_case(lib, name, scramble)
 
 
+@pytest.mark.parametrize("name", ["persub_cart2d_4x5", "persub_tri2d_4x4", "persub_tet3d_2x2x3"])
+@pytest.mark.parametrize("scramble", [False, True])
+def test_boundary_conditions_per_subface_on_a_grid_with_periodic_faces(lib, name, scramble):
+    P.check_periodic_subface_case(lib, name, scramble)
+
+
 def test_device_resident_vectors(lib):
     import torch
 
