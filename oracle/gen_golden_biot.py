@@ -25,8 +25,10 @@ COUP = ("scalar_gradient", "displacement_divergence", "boundary_displacement_div
         "bound_displacement_pressure")
 
 
-def save(name, g, C, bc, alphas, keys=COUP):
+def save(name, g, C, bc, alphas, keys=COUP, more_params=None, extra=None):
     params = {"fourth_order_tensor": C, "bc": bc, "inverter": "python", "scalar_vector_mappings": alphas}
+    if more_params:
+        params.update(more_params)
     data = pp.initialize_data({}, "mechanics", params)
     pp.Biot("mechanics").discretize(g, data)
     mats = data[pp.DISCRETIZATION_MATRICES]["mechanics"]
@@ -44,6 +46,8 @@ def save(name, g, C, bc, alphas, keys=COUP):
             pack_csr(f"ref_{k}__{key}", mats[k][key], store)
     for k in ("stress", "bound_stress"):
         pack_csr("ref_" + k, mats[k], store)
+    if extra:
+        store.update(extra)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **store)
     print(f"{name:34s} cells={g.num_cells:4d}  {os.path.getsize(path)/1024:.0f} KiB")

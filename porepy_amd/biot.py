@@ -11,7 +11,8 @@ import numpy as np
 
 from . import _lib
 from .grid import grid_to_raw
-from .mpfa import determine_eta, estimate_device_bytes, note_ignored_parameters, partition_cells, plan_subproblems
+from .mpfa import (determine_eta, estimate_device_bytes, note_ignored_parameters, partition_cells, plan_subproblems,
+                   sps_nnz, subface_order)
 from .partial import active_indices
 from .mpsa import Mpsa
 from .mpsa import _KEYS as _MECH_KEYS
@@ -63,10 +64,18 @@ class Biot(Mpsa):
                 a = SecondOrderTensor(float(a) * np.ones(sd.num_cells))
             alphas.append(np.asarray(a.values, dtype=float))
         eta = pd.get("mpsa_eta", None)
+        eta_sub = None
         if eta is None:
             eta = determine_eta(sd)
         elif np.asarray(eta).size != 1:
-            raise NotImplementedError("continuity points per sub-face are not covered for the Biot coupling terms")
+            # one continuity point per sub-face (_fvutils.py:222-277), in the storage order of the caller's face_nodes
+            eta_sub = np.asarray(eta, dtype=float).ravel()
+            if eta_sub.size != sps_nnz(sd.face_nodes):
+                raise ValueError("size of eta must either be 1 or number of subfaces")
+            if partial or update or pd.get("partition_arguments"):
+                raise NotImplementedError("continuity points per sub-face: full Biot discretization in one piece only")
+            eta_sub = eta_sub[subface_order(sd.face_nodes)]
+            eta = 0.0
         # the reference's Biot reconstructs the displacement traces at the continuity points whatever
         # ``reconstruction_eta`` says (biot.py:803-805 calls _reconstruct_displacement with eta; the key is never read):
         # the same here, with a note
@@ -86,6 +95,7 @@ class Biot(Mpsa):
         ctx.mpsa_set_params(np.asarray(C.values), sd.cell_volumes, bnd.is_dir, bnd.is_neu, float(eta), is_rob=is_rob,
                             robin_weight=getattr(bnd, "robin_weight", None) if is_rob is not None else None,
                             basis=basis)
+        ctx.mpsa_set_subface_eta(eta_sub)  # (None: the scalar eta of mpsa_set_params)
         ctx.biot_set_alphas(alphas)
         if partial and not alphas:
             return Mpsa.discretize(self, sd, data)

@@ -257,6 +257,7 @@ class BiotCase:
                    "robin_weight": z["bc_robin_weight"]}
         self.stiffness = z["stiffness"]
         self.alphas = {str(k): z[f"alpha_{k}"] for k in z["alpha_keys"]}
+        self.eta_sub = z["eta_sub"] if "eta_sub" in z.files else None  # continuity points per sub-face (sorted CSC order)
 
         def mat(prefix):
             shape = tuple(int(v) for v in z[prefix + "_shape"])

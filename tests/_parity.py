@@ -753,11 +753,12 @@ def check_biot_case(lib, name: str):
     bc.robin_weight = c.bc["robin_weight"]
     C = type("C", (), {"values": c.stiffness})()
     maps = {k: type("A", (), {"values": v})() for k, v in c.alphas.items()}
-    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "scalar_vector_mappings": maps})
+    more = {} if c.eta_sub is None else {"mpsa_eta": c.eta_sub}  # (round 5: continuity points per sub-face)
+    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "scalar_vector_mappings": maps, **more})
     d = pa.Biot("mechanics", library=lib)
     d.discretize(g, data)
     md = data[pa.DISCRETIZATION_MATRICES]["mechanics"]
-    ora = so.discretize(c.grid, c.stiffness, c.bc, alphas=c.alphas)
+    ora = so.discretize(c.grid, c.stiffness, c.bc, alphas=c.alphas, eta=c.eta_sub)
     for k in ("stress", "bound_stress"):
         assert rel_max_err(md[k], c.ref_mech[k]) < TOL, (name, k)
     for k in BIOT_KEYS:
@@ -770,7 +771,7 @@ def check_biot_case(lib, name: str):
             assert rel_max_err(M, c.ref[k][key]) < TOL, (name, k, key)
     # ``reconstruction_eta`` is never read by the reference's Biot (biot.py:803-805 reconstructs at eta): the same matrices
     data2 = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "scalar_vector_mappings": maps,
-                                                "reconstruction_eta": 0.05})
+                                                "reconstruction_eta": 0.05, **more})
     pa.Biot("mechanics", library=lib).discretize(g, data2)
     md2 = data2[pa.DISCRETIZATION_MATRICES]["mechanics"]
     for k in ("bound_displacement_cell", "bound_displacement_face"):

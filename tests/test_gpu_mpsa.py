@@ -71,7 +71,8 @@ def test_amg_block_preconditioner_for_mechanics(lib):
     assert info["iterations"] * 2 < base["iterations"], (info, base)
 
 
-@pytest.mark.parametrize("name", ["biot_tri2d_3x3_mixed", "biot_cart2d_3x2_dir", "biot_tet_2x2x2_mixed"])
+@pytest.mark.parametrize("name", ["biot_tri2d_3x3_mixed", "biot_cart2d_3x2_dir", "biot_tet_2x2x2_mixed",
+                                  "biot_etasub_tri2d_3x3", "biot_etasub_tet_2x2x2"])
 def test_biot_coupling_terms(lib, name):
     P.check_biot_case(lib, name)
 

@@ -14,7 +14,7 @@ NAMES = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_
 @pytest.mark.parametrize("name", NAMES)
 def test_biot_oracle_matches_reference(name):
     c = BiotCase(name)
-    out = so.discretize(c.grid, c.stiffness, c.bc, alphas=c.alphas)
+    out = so.discretize(c.grid, c.stiffness, c.bc, alphas=c.alphas, eta=c.eta_sub)  # (eta None: the default point)
     for k in ("stress", "bound_stress"):
         assert rel_max_err(out[k], c.ref_mech[k]) < 1e-10, (name, k)
     for k in BIOT_KEYS:
