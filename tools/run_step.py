@@ -25,7 +25,11 @@ else:
 ctx = pa.Context(0)
 ctx.set_grid(raw)
 ctx.set_params(Kvals, flags, None, eta)
-for _ in range(2):
+moving = os.environ.get("PFV_RUN_STEP_MOVING", "0") != "0"  # a new field for the second step (what bench.py times)
+for it in range(2):
+    if moving and it == 1:
+        fac = np.exp(0.5 * np.random.default_rng(7).standard_normal(Kvals.shape[-1]))
+        ctx.set_permeability(np.ascontiguousarray(Kvals * fac[None, None, :]))
     ctx.discretize(rebuild_topology=True)
     ctx.assemble(bv, None, src)
     x, info = ctx.solve("bicgstab", rtol=1e-13, maxit=2000, raise_on_fail=False, precond="amg")
