@@ -230,3 +230,27 @@ def test_operator_trees_of_the_reference_evaluated_with_device_jacobians(variant
     assert "error" not in t, t
     assert t["dofs"] == 440 and t["equations"] == 7 and t["same_nonzero_pattern"] is True and t["rhs_identical"] is True
     assert t["jac_rel_err"] < 1e-15
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("mode, decades, seeds", [("", None, 6), ("special", None, 4), ("contrast", "2,6", 8)])
+def test_fixed_seed_slice_of_the_differential_driver_against_the_reference(variant, mode, decades, seeds):
+    """``tools/fuzz_vs_reference.py`` (random grids, tensors, conditions through PorePy itself and through the operator
+    classes of this package) on a fixed slice of seeds: plain, the special legs (conditions per sub-face, partial
+    discretization, tilted grids, TPFA, continuity points per sub-face), and permeability / stiffness contrasts of
+    1e2 ... 1e6 between neighbouring cells -- where a verdict of the local inversions differs it must be a singular or
+    near-singular INPUT by the 60-digit inversion of the reference's own systems.  No suspicious case."""
+    env = oracle.ref_env(extra_last=[ROOT], prefer_archive=(variant == "product"))
+    if env is None:
+        pytest.skip("reference PorePy not present (neither /root/reference nor oracle/_ref/porepy_ref.zip)")
+    if variant == "product":
+        env["PFV_FUZZ_DEVICE"] = "1"
+    if decades:
+        env["PFV_FUZZ_DECADES"] = decades
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    args = [str(seeds), "424242"] + ([mode] if mode else [])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_vs_reference.py"), *args], env=env, cwd="/tmp",
+                       capture_output=True, text=True, timeout=900)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert tail == "suspicious cases: 0", (r.stdout[-2500:], r.stderr[-1500:])
+    assert r.stdout.count("max rel err vs reference") >= seeds  # (it did compare)
