@@ -1530,7 +1530,13 @@ pfv_status pfv_amg_setup_sharded(pfv_ctx* h, int64_t n_own, const pfv_shard_hook
     V.max_row = P.max_row;
     V.indptr.p = P.indptr.p;
     V.indices.p = P.indices.p;
-    pfv::amg_setup(*h, amg, V, h->active.val, bs, nullptr, nullptr);
+    // the windows of the owned rows (built beside the face kernel, or by the previous sharded solve): the windows of the
+    // strength-filtered operator are derived from them instead of hashed and sorted from scratch (spmv_win.inc: win_derive)
+    const pfv::WinCsr* win0 = (bs == 1 && h->win_rows.ok && h->win_rows_for == P.indices.p && h->win_rows_n == n_own &&
+                               h->win_rows.nrows == n_own && pfv::env_int("PFV_SHARD_WIN0", 1) != 0)
+                                  ? &h->win_rows
+                                  : nullptr;
+    pfv::amg_setup(*h, amg, V, h->active.val, bs, nullptr, win0);
     h->stats.amg_setup_ms = amg.setup_ms;
     h->stats.amg_operator_complexity = amg.op_complexity;
     h->stats.amg_levels = (int64_t)(amg.nlev + (amg.dist->glob ? amg.dist->glob->nlev - 1 : 0));
