@@ -470,7 +470,8 @@ def config_c5(live: bool = False):
 HEADLINE_PATTERN = os.path.join(ROOT, "tests", "golden", "headline_flux_pattern_69.npz")
 
 
-def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_pattern: bool = False):
+def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_pattern: bool = False, n_side: int = 69,
+                     library=None, fixture: str | None = None):
     """Whole-grid parity datum at the headline size.  The REFERENCE was run on all 1 971 054
     tetrahedra of make_problem(69) (``oracle/gen_golden_headline_pattern.py``: pp.Mpfa with 12 sub-problems, 20 minutes
     of host time; the same topology and geometry arrays the device gets) and left, in
@@ -478,14 +479,14 @@ def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_patt
     ``flux`` and a digest of their (row, column) pairs.  Here: the device's flux pattern on the same grid must have
     exactly those row lengths in every row that is not a Neumann boundary row (where the true entries are all zero
     and what either side stores is cancellation noise: there the reference's stored entries are a subset)."""
-    z = np.load(HEADLINE_PATTERN)
+    z = np.load(fixture or (HEADLINE_PATTERN if n_side == 69 else HEADLINE_PATTERN.replace("_69.npz", f"_{n_side}.npz")))
     tot = json.loads(str(z["totals"]))
     t0 = time.perf_counter()
-    g, K, bc, bv, src = make_problem(69)
+    g, K, bc, bv, src = make_problem(n_side)
     nf = g.num_faces
     ref_len = z["row_len"].astype(np.int64)
     neu = np.unpackbits(z["neumann_row"])[:nf].astype(bool)
-    ctx = pa.Context(device_index)
+    ctx = pa.Context(device_index) if library is None else pa.Context(device_index, library)
     try:
         ctx.set_grid(pa.grid_to_raw(g))
         ctx.set_params(K.values, pa.bc_flags(bc), None, 1.0 / 3.0)
@@ -493,6 +494,7 @@ def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_patt
         ctx.assemble(bv, None, src)
         x, info = ctx.solve("bicgstab", rtol=rtol, maxit=20000, raise_on_fail=False, precond=precond)
         F = ctx.matrix(pa._lib.MAT_FLUX)
+        BF = ctx.matrix(pa._lib.MAT_BOUND_FLUX) if "flux_value_digest" in z.files else None
         nnz_sys = int(ctx.matrix_info(pa._lib.MAT_SYSTEM)[2])
     finally:
         ctx.close()
@@ -513,6 +515,31 @@ def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_patt
            "seconds_incl_host_grid": time.perf_counter() - t0}
     out["pattern_row_lengths_equal"] = (out["rows_with_a_different_length_outside_neumann_rows"] == 0 and
                                         out["neumann_rows_where_the_reference_stores_more"] == 0)
+    if "flux_value_digest" in z.files:
+        # VALUE datum of the same reference run (round 5, late): per block of consecutive rows (1024 blocks) sum |a|,
+        # sum a^2 and a column-weighted sum of flux and bound_flux, and the pressure field of the reference's own
+        # assemble_matrix_rhs + scipy BiCGStab (rtol 1e-13) -- relative differences, block by block
+        from oracle.gen_golden_headline_pattern import value_digest, vector_digest  # (checker: tests / bench only)
+
+        def worst(dev, ref):
+            scale = np.maximum(np.abs(ref[0]), 1e-300)  # (sum |a| of the block: the scale of all three rows)
+            return [float(np.max(np.abs(dev[0] - ref[0]) / scale)),
+                    float(np.max(np.abs(dev[1] - ref[1]) / np.maximum(np.abs(ref[1]), 1e-300))),
+                    float(np.max(np.abs(dev[2] - ref[2]) / scale))]
+
+        out["values_vs_reference"] = {
+            "blocks": int(z["flux_value_digest"].shape[1]),
+            "flux_worst_rel_diff_abs_sq_weighted": worst(value_digest(F, rows_mask=~neu), z["flux_value_digest"]),
+            "bound_flux_worst_rel_diff_abs_sq_weighted": worst(value_digest(BF), z["bound_flux_value_digest"]),
+            "pressure_norm_reference": float(z["pressure_norm"][0]),
+            "pressure_norm_rel_diff": float(abs(np.linalg.norm(x) - z["pressure_norm"][0]) / z["pressure_norm"][0]),
+            "reference_solve": json.loads(str(z["solve"])),
+        }
+        pd, pr = vector_digest(x), z["pressure_digest"]
+        out["values_vs_reference"]["pressure_block_sums_worst_rel_diff"] = float(
+            np.max(np.abs(pd[0] - pr[0]) / np.maximum(np.sqrt(pr[1] * np.maximum(1, -(-x.size // pr.shape[1]))), 1e-300)))
+        out["values_vs_reference"]["pressure_block_squares_worst_rel_diff"] = float(
+            np.max(np.abs(pd[1] - pr[1]) / np.maximum(pr[1], 1e-300)))
     if want_pattern:
         out["_pattern"] = (F.indptr, F.indices, ~neu, int(z["digest_rows"][0]))
     return out

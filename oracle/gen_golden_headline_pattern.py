@@ -13,6 +13,9 @@ inverter) leaves the flux matrix; stored in tests/golden/headline_flux_pattern_<
   neumann_row  packed bits: rows of Neumann boundary faces (their true entries are all zero: what either side stores
                there is cancellation noise, the reference's stored noise is a subset of the structural stencil)
   totals       nnz of flux / bound_flux / vector_source, seconds of the run
+and (round 5, late) a VALUE datum: ``flux_value_digest`` / ``bound_flux_value_digest`` (3 x 1024: per block of consecutive
+rows sum |a|, sum a^2, sum a w(column)), ``pressure_digest`` / ``pressure_norm`` of the field the reference's own
+``assemble_matrix_rhs`` + scipy BiCGStab (rtol 1e-13) give on that grid.
 """
 from __future__ import annotations
 
@@ -52,7 +55,36 @@ def headline_digest(indptr, indices, rows_mask) -> int:
     return int(total)
 
 
-def main(n_side: int = 69, num_sub: int = 12):
+N_BLOCKS = 1024
+
+
+def value_digest(M, n_blocks: int = N_BLOCKS, rows_mask=None):
+    """Per block of consecutive rows (n_blocks blocks) of a CSR matrix: sum |a|, sum a^2, and sum a * w(column) with
+    w(c) = 0.5 + frac(c * golden ratio) -- fixed weights in [0.5, 1.5) that do not annihilate rows summing to zero.
+    The same function is applied to the device's matrix by bench.whole_grid_check.  rows_mask: rows that count."""
+    M = sps.csr_matrix(M)
+    n = M.shape[0]
+    rows_per = -(-n // n_blocks)
+    row_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(M.indptr))
+    blk = row_of // rows_per
+    w = 0.5 + np.mod(M.indices.astype(np.float64) * 0.6180339887498949, 1.0)
+    a = M.data
+    if rows_mask is not None:  # (rows left out: the Neumann boundary rows of flux, whose true entries are all zero)
+        a = np.where(np.asarray(rows_mask, bool)[row_of], a, 0.0)
+    return np.stack([np.bincount(blk, weights=np.abs(a), minlength=n_blocks),
+                     np.bincount(blk, weights=a * a, minlength=n_blocks),
+                     np.bincount(blk, weights=a * w, minlength=n_blocks)])
+
+
+def vector_digest(x, n_blocks: int = N_BLOCKS):
+    """Per block of consecutive entries: sum x, sum x^2."""
+    x = np.asarray(x, dtype=float)
+    rows_per = -(-x.size // n_blocks)
+    blk = np.arange(x.size, dtype=np.int64) // rows_per
+    return np.stack([np.bincount(blk, weights=x, minlength=n_blocks), np.bincount(blk, weights=x * x, minlength=n_blocks)])
+
+
+def main(n_side: int = 69, num_sub: int = 12, out_dir: str | None = None):
     import porepy as pp
 
     import _reference_patch_script as rps
@@ -86,7 +118,28 @@ def main(n_side: int = 69, num_sub: int = 12):
     row_len = np.diff(F.indptr)
     assert row_len.max() < 256
     dig = headline_digest(F.indptr, F.indices, ~neumann_row)
+    # ---- value datum (round 5, late): block digests of flux / bound_flux, and the pressure field of the assembled system
+    t3 = time.perf_counter()
+    disc = pp.Mpfa("flow")
+    A, b = disc.assemble_matrix_rhs(gr, data)  # (fv_elliptic.py:67-112: div @ flux, -div @ bound_flux @ bc values)
+    b = b + np.asarray(src, dtype=float)       # the integrated source of make_problem, as the device's assemble adds it
+    A = sps.csr_matrix(A)
+    import scipy.sparse.linalg as spla
+
+    d = A.diagonal()
+    M = spla.LinearOperator(A.shape, lambda v: v / d)
+    its = [0]
+    p, flag = spla.bicgstab(A, b, rtol=1e-13, atol=0.0, maxiter=20000, M=M, callback=lambda _x: its.__setitem__(0, its[0] + 1))
+    res = float(np.linalg.norm(b - A @ p) / np.linalg.norm(b))
+    t4 = time.perf_counter()
     out = {
+        "flux_value_digest": value_digest(F, rows_mask=~neumann_row),
+        "bound_flux_value_digest": value_digest(md["bound_flux"]),
+        "pressure_digest": vector_digest(p),
+        "pressure_norm": np.array([float(np.linalg.norm(p))]),
+        "solve": np.array(json.dumps({"iterations": its[0], "flag": int(flag), "true_rel_residual": res,
+                                      "solver": "scipy BiCGStab + Jacobi, rtol 1e-13", "seconds": t4 - t3,
+                                      "system_nnz": int(A.nnz)})),
         "row_len": row_len.astype(np.uint8),
         "neumann_row": np.packbits(neumann_row),
         "digest_rows": np.array([dig], dtype=np.uint64),
@@ -97,10 +150,11 @@ def main(n_side: int = 69, num_sub: int = 12):
             "stored_exact_zeros_in_flux": int((F.data == 0).sum()),
             "discretize_s": t2 - t1, "grid_s": t1 - t0, "porepy_from": os.path.dirname(pp.__file__)})),
     }
-    path = os.path.join(ROOT, "tests", "golden", f"headline_flux_pattern_{n_side}.npz")
+    path = os.path.join(out_dir or os.path.join(ROOT, "tests", "golden"), f"headline_flux_pattern_{n_side}.npz")
     np.savez_compressed(path, **out)
     print(out["totals"], os.path.getsize(path) / 1e6, "MB", flush=True)
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 69, int(sys.argv[2]) if len(sys.argv) > 2 else 12)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 69, int(sys.argv[2]) if len(sys.argv) > 2 else 12,
+         sys.argv[3] if len(sys.argv) > 3 else None)

@@ -392,6 +392,15 @@ def test_whole_headline_grid_pattern_against_the_reference_run_on_the_whole_grid
     assert out["neumann_rows_where_the_reference_stores_more"] == 0, out
     assert headline_digest(indptr, indices, rows) == ref_digest
     assert out["device_rel_residual"] < 1e-12
+    # ... and the VALUES of the same run of the reference (round 5, late): per block of 3 878 consecutive rows the sums
+    # |a|, a^2 and a column-weighted sum of flux (Neumann rows left out) and of bound_flux; the pressure field of the
+    # reference's own assemble_matrix_rhs + scipy BiCGStab to 1e-13 (1 062 iterations, 539 s on the build host)
+    v = out["values_vs_reference"]
+    print("whole-grid values vs reference:", v)
+    assert v["blocks"] == 1024
+    assert max(v["flux_worst_rel_diff_abs_sq_weighted"]) < 1e-10, v
+    assert max(v["bound_flux_worst_rel_diff_abs_sq_weighted"]) < 1e-10, v
+    assert v["pressure_norm_rel_diff"] < 1e-10, v
 
 
 def test_config_c2_all_matrices_on_patches(lib):

@@ -254,3 +254,29 @@ def test_fixed_seed_slice_of_the_differential_driver_against_the_reference(varia
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert tail == "suspicious cases: 0", (r.stdout[-2500:], r.stderr[-1500:])
     assert r.stdout.count("max rel err vs reference") >= seeds  # (it did compare)
+
+
+def test_whole_grid_datum_machinery_on_a_small_grid(tmp_path):
+    """The whole-grid datum of the headline size (pattern: row lengths + digest; values: block digests of flux and
+    bound_flux, the pressure field) is made by ``oracle/gen_golden_headline_pattern.py`` from a run of the reference on
+    the whole grid and consumed by ``bench.whole_grid_check``.  Here the same two functions on a 3 072-cell grid, the
+    reference run on the spot, the kernels through the host-emulation build: what the GPU test asserts at 1 971 054
+    cells must hold here to rounding."""
+    env = oracle.ref_env(extra_last=[ROOT])
+    if env is None:
+        pytest.skip("reference PorePy not present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden_headline_pattern.py"), "8", "2", str(tmp_path)],
+                       env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+    fx = os.path.join(str(tmp_path), "headline_flux_pattern_8.npz")
+    assert os.path.exists(fx), r.stderr[-2000:]
+    import bench
+    import porepy_amd as pa
+    from oracle.gen_golden_headline_pattern import headline_digest
+    from tests import _parity as P
+
+    out = bench.whole_grid_check(pa, 0, 1e-13, "amg", want_pattern=True, n_side=8, library=P.emulation_library(), fixture=fx)
+    indptr, indices, rows, ref_digest = out.pop("_pattern")
+    assert out["pattern_row_lengths_equal"] and headline_digest(indptr, indices, rows) == ref_digest
+    v = out["values_vs_reference"]
+    assert max(v["flux_worst_rel_diff_abs_sq_weighted"]) < 1e-12 and max(v["bound_flux_worst_rel_diff_abs_sq_weighted"]) < 1e-12
+    assert v["pressure_norm_rel_diff"] < 1e-10 and v["pressure_block_squares_worst_rel_diff"] < 1e-9
