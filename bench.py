@@ -470,6 +470,37 @@ def config_c5(live: bool = False):
 HEADLINE_PATTERN = os.path.join(ROOT, "tests", "golden", "headline_flux_pattern_69.npz")
 
 
+N_BLOCKS = 1024
+
+
+def value_digest(M, n_blocks: int = N_BLOCKS, rows_mask=None):
+    """Per block of consecutive rows (n_blocks blocks) of a CSR matrix: sum |a|, sum a^2, and sum a * w(column) with
+    w(c) = 0.5 + frac(c * golden ratio) -- fixed weights in [0.5, 1.5) that do not annihilate rows summing to zero.
+    The same function is applied to the device's matrix by bench.whole_grid_check.  rows_mask: rows that count."""
+    import scipy.sparse as sps
+
+    M = sps.csr_matrix(M)
+    n = M.shape[0]
+    rows_per = -(-n // n_blocks)
+    row_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(M.indptr))
+    blk = row_of // rows_per
+    w = 0.5 + np.mod(M.indices.astype(np.float64) * 0.6180339887498949, 1.0)
+    a = M.data
+    if rows_mask is not None:  # (rows left out: the Neumann boundary rows of flux, whose true entries are all zero)
+        a = np.where(np.asarray(rows_mask, bool)[row_of], a, 0.0)
+    return np.stack([np.bincount(blk, weights=np.abs(a), minlength=n_blocks),
+                     np.bincount(blk, weights=a * a, minlength=n_blocks),
+                     np.bincount(blk, weights=a * w, minlength=n_blocks)])
+
+
+def vector_digest(x, n_blocks: int = N_BLOCKS):
+    """Per block of consecutive entries: sum x, sum x^2."""
+    x = np.asarray(x, dtype=float)
+    rows_per = -(-x.size // n_blocks)
+    blk = np.arange(x.size, dtype=np.int64) // rows_per
+    return np.stack([np.bincount(blk, weights=x, minlength=n_blocks), np.bincount(blk, weights=x * x, minlength=n_blocks)])
+
+
 def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_pattern: bool = False, n_side: int = 69,
                      library=None, fixture: str | None = None):
     """Whole-grid parity datum at the headline size.  The REFERENCE was run on all 1 971 054
@@ -519,8 +550,6 @@ def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_patt
         # VALUE datum of the same reference run (round 5, late): per block of consecutive rows (1024 blocks) sum |a|,
         # sum a^2 and a column-weighted sum of flux and bound_flux, and the pressure field of the reference's own
         # assemble_matrix_rhs + scipy BiCGStab (rtol 1e-13) -- relative differences, block by block
-        from oracle.gen_golden_headline_pattern import value_digest, vector_digest  # (checker: tests / bench only)
-
         def worst(dev, ref):
             scale = np.maximum(np.abs(ref[0]), 1e-300)  # (sum |a| of the block: the scale of all three rows)
             return [float(np.max(np.abs(dev[0] - ref[0]) / scale)),

@@ -55,33 +55,7 @@ def headline_digest(indptr, indices, rows_mask) -> int:
     return int(total)
 
 
-N_BLOCKS = 1024
-
-
-def value_digest(M, n_blocks: int = N_BLOCKS, rows_mask=None):
-    """Per block of consecutive rows (n_blocks blocks) of a CSR matrix: sum |a|, sum a^2, and sum a * w(column) with
-    w(c) = 0.5 + frac(c * golden ratio) -- fixed weights in [0.5, 1.5) that do not annihilate rows summing to zero.
-    The same function is applied to the device's matrix by bench.whole_grid_check.  rows_mask: rows that count."""
-    M = sps.csr_matrix(M)
-    n = M.shape[0]
-    rows_per = -(-n // n_blocks)
-    row_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(M.indptr))
-    blk = row_of // rows_per
-    w = 0.5 + np.mod(M.indices.astype(np.float64) * 0.6180339887498949, 1.0)
-    a = M.data
-    if rows_mask is not None:  # (rows left out: the Neumann boundary rows of flux, whose true entries are all zero)
-        a = np.where(np.asarray(rows_mask, bool)[row_of], a, 0.0)
-    return np.stack([np.bincount(blk, weights=np.abs(a), minlength=n_blocks),
-                     np.bincount(blk, weights=a * a, minlength=n_blocks),
-                     np.bincount(blk, weights=a * w, minlength=n_blocks)])
-
-
-def vector_digest(x, n_blocks: int = N_BLOCKS):
-    """Per block of consecutive entries: sum x, sum x^2."""
-    x = np.asarray(x, dtype=float)
-    rows_per = -(-x.size // n_blocks)
-    blk = np.arange(x.size, dtype=np.int64) // rows_per
-    return np.stack([np.bincount(blk, weights=x, minlength=n_blocks), np.bincount(blk, weights=x * x, minlength=n_blocks)])
+from bench import N_BLOCKS, value_digest, vector_digest  # noqa: E402  (the digest functions live with their consumer)
 
 
 def main(n_side: int = 69, num_sub: int = 12, out_dir: str | None = None):
