@@ -2120,3 +2120,77 @@ def batch_hands_special_inputs_to_the_single_grid_path(lib):
             assert a.shape == b.shape and abs(a - b).max() == 0.0, (g.num_cells, k)
     assert items[2][1][pa.PARAMETERS]["flow"]["active_faces"].size < gs[2].num_faces  # (the partial one stayed partial)
     return stats
+
+
+# ------------------------------------------------------------------------------------ MPSA, whole-grid value datum
+def mpsa_whole_grid_problem(n: int):
+    """The problem of oracle/gen_golden_mpsa_whole_grid.py (the BASELINE configs[3] family: perturbed tetrahedral box,
+    rollers on the low faces, traction on top) with heterogeneous Lame parameters: (grid, mu, lambda, is_dir, is_neu,
+    boundary values face-major)."""
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.2 / n)
+    nc, nf = g.num_cells, g.num_faces
+    rng = np.random.default_rng(5)
+    mu, lam = np.exp(0.3 * rng.standard_normal(nc)), np.exp(0.3 * rng.standard_normal(nc))
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    fc = g.face_centers
+    for axis in range(3):
+        roll = bf[fc[axis, bf] < 1e-9]
+        bc.is_dir[axis, roll] = True
+        bc.is_neu[axis, roll] = False
+    bv = np.zeros((3, nf))
+    top = bf[fc[2, bf] > 1 - 1e-9]
+    bv[2, top] = -g.face_areas[top]
+    bv[0, top] = 0.3 * g.face_areas[top]  # (a shear component: the field is not the uniaxial one)
+    return g, mu, lam, np.asarray(bc.is_dir, bool), np.asarray(bc.is_neu, bool), bv.ravel("F")
+
+
+def mpsa_stress_rows_that_count(raw, is_neu):
+    """Rows (nd * face + component) of ``stress`` outside the Neumann components of boundary faces: there the true
+    entries are all zero and what either side stores is cancellation noise (as the Neumann rows of ``flux``)."""
+    nd = int(raw["dim"])
+    nf = raw["face_centers"].shape[1]
+    sides = np.bincount(np.asarray(raw["cf_indices"]), minlength=nf)
+    noise = (sides == 1)[None, :] & np.asarray(is_neu, bool)
+    return ~noise.ravel("F")
+
+
+def mpsa_whole_grid_check(lib, n: int = 16):
+    """All four MPSA matrices and the displacement field on the WHOLE grid against a run of the reference on it
+    (tests/golden/mpsawhole_<n>.npz): block digests of the values (bench.value_digest), norm and block sums of u."""
+    import json
+
+    import bench
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"mpsawhole_{n}.npz"))
+    info = json.loads(str(z["info"]))
+    g, mu, lam, is_dir, is_neu, bvf = mpsa_whole_grid_problem(n)
+    assert g.num_cells == info["cells"]
+    C = pa.FourthOrderTensor(mu, lam)
+    ctx = pa.Context(0, lib)
+    try:
+        ctx.set_grid(pa.grid_to_raw(g))
+        ctx.mpsa_set_params(C.values, g.cell_volumes, is_dir, is_neu, 1.0 / 3.0)
+        ctx.mpsa_discretize(rebuild_topology=True)
+        ctx.mpsa_assemble(bvf, None)
+        u, sol = ctx.solve("bicgstab", rtol=1e-13, maxit=50000, n=3 * g.num_cells, raise_on_fail=False, precond="amg")
+        mats = {k: ctx.matrix(MPSA_WHICH[k]) for k in MPSA_KEYS}
+    finally:
+        ctx.close()
+    out = {"cells": int(g.num_cells), "iterations": int(sol["iterations"]), "rel_residual": float(sol["rel_residual"]),
+           "reference": info}
+    blocks = z["stress_digest"].shape[1]
+    for k in MPSA_KEYS:
+        mask = mpsa_stress_rows_that_count(pa.grid_to_raw(g), is_neu) if k == "stress" else None
+        dev, ref = bench.value_digest(mats[k], blocks, rows_mask=mask), z[k + "_digest"]
+        scale = np.maximum(np.abs(ref[0]), 1e-300)
+        out[k] = [float(np.max(np.abs(dev[0] - ref[0]) / scale)),
+                  float(np.max(np.abs(dev[1] - ref[1]) / np.maximum(np.abs(ref[1]), 1e-300))),
+                  float(np.max(np.abs(dev[2] - ref[2]) / scale))]
+        assert mats[k].nnz >= info["nnz"][k], (k, mats[k].nnz, info["nnz"][k])  # (the reference drops exact zeros)
+    out["u_norm_rel_diff"] = float(abs(np.linalg.norm(u) - z["u_norm"][0]) / z["u_norm"][0])
+    ud, ur = bench.vector_digest(u, blocks), z["u_digest"]
+    out["u_block_squares_worst_rel_diff"] = float(np.max(np.abs(ud[1] - ur[1]) / np.maximum(ur[1], 1e-300)))
+    return out

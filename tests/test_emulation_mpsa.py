@@ -176,3 +176,14 @@ def test_interaction_region_larger_than_lds(lib):
 @pytest.mark.parametrize("name", ["biot_tri2d_3x3_mixed", "biot_tet_2x2x2_mixed"])
 def test_biot_partition_arguments_discretize_in_pieces(lib, name):
     P.biot_pieces_case(lib, name)
+
+
+def test_all_four_matrices_and_the_displacement_field_on_a_whole_grid_against_the_reference(lib):
+    """Whole-grid VALUE datum (oracle/gen_golden_mpsa_whole_grid.py): the reference's pp.Mpsa was run on every cell of a
+    10 368-cell perturbed tetrahedral box of the configs[3] family (heterogeneous Lame parameters, rollers, traction with a
+    shear component) with its own assemble_matrix_rhs and a scipy solve; the kernels (host-emulation build) reproduce the
+    block digests of all four matrices and the displacement field."""
+    out = P.mpsa_whole_grid_check(lib, 12)
+    for k in P.MPSA_KEYS:
+        assert max(out[k]) < 1e-12, (k, out[k])
+    assert out["u_norm_rel_diff"] < 1e-10 and out["u_block_squares_worst_rel_diff"] < 1e-9, out
