@@ -8,7 +8,7 @@ bound_displacement_face, and the displacement field (norm, per-block sums).  The
 
 TEST INFRASTRUCTURE; build container only:
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/repo/oracle/shim:/root/reference/src:/root/repo \
-      python /root/repo/oracle/gen_golden_mpsa_whole_grid.py [n_side = 16]
+      python /root/repo/oracle/gen_golden_mpsa_whole_grid.py [n_side = 16] [num_subproblems = 1]
 """
 from __future__ import annotations
 
@@ -29,7 +29,7 @@ KEYS = ("stress", "bound_stress", "bound_displacement_cell", "bound_displacement
 BLOCKS = 256
 
 
-def main(n: int = 16):
+def main(n: int = 16, num_sub: int = 1):
     import porepy as pp
 
     import _reference_patch_script as rps
@@ -46,6 +46,8 @@ def main(n: int = 16):
     C = pp.FourthOrderTensor(mu, lam)
     data = pp.initialize_data({}, "mechanics", {"fourth_order_tensor": C, "bc": bc, "bc_values": bvf, "inverter": "python",
                                                 "mpsa_eta": 1.0 / 3.0, "source": np.zeros(3 * gr.num_cells)})
+    if num_sub > 1:  # (memory-bounded run of the reference: mpsa.py:201-207, _fvutils.subproblems)
+        data[pp.PARAMETERS]["mechanics"]["partition_arguments"] = {"num_subproblems": int(num_sub)}
     d = pp.Mpsa("mechanics")
     t1 = time.perf_counter()
     d.discretize(gr, data)
@@ -66,7 +68,7 @@ def main(n: int = 16):
     out["u_digest"] = vector_digest(u, BLOCKS)
     out["u_norm"] = np.array([float(np.linalg.norm(u))])
     out["info"] = np.array(json.dumps({
-        "n_side": n, "cells": int(gr.num_cells), "faces": int(gr.num_faces), "dofs": int(A.shape[0]),
+        "n_side": n, "num_subproblems": num_sub, "cells": int(gr.num_cells), "faces": int(gr.num_faces), "dofs": int(A.shape[0]),
         "nnz": {k: int(sps.csr_matrix(md[k]).nnz) for k in KEYS}, "system_nnz": int(A.nnz),
         "discretize_s": t2 - t1, "solve_s": t3 - t2, "grid_s": t1 - t0, "iterations": its[0], "flag": int(flag),
         "true_rel_residual": res, "solver": "scipy BiCGStab + Jacobi, rtol 1e-13"}))
@@ -76,4 +78,4 @@ def main(n: int = 16):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 16)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 16, int(sys.argv[2]) if len(sys.argv) > 2 else 1)

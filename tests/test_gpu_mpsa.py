@@ -146,15 +146,17 @@ def test_biot_partition_arguments_discretize_in_pieces(lib, name):
     P.biot_pieces_case(lib, name)
 
 
-def test_all_four_matrices_and_the_displacement_field_on_a_whole_grid_against_the_reference(lib):
-    """Whole-grid VALUE datum (oracle/gen_golden_mpsa_whole_grid.py): the reference's pp.Mpsa was run on every one of the
-    48 000 cells (144 000 unknowns) of a perturbed tetrahedral box of the configs[3] family -- heterogeneous Lame
-    parameters, rollers, traction with a shear component; 269 s of discretization, its own assemble_matrix_rhs, scipy
-    BiCGStab to 1e-13 -- and left block digests of stress (46.6 M entries), bound_stress, bound_displacement_cell,
-    bound_displacement_face and of the displacement field.  The device reproduces all of them."""
-    out = P.mpsa_whole_grid_check(lib, 20)
+@pytest.mark.parametrize("n, cells", [(20, 48000), (32, 196608)])
+def test_all_four_matrices_and_the_displacement_field_on_a_whole_grid_against_the_reference(lib, n, cells):
+    """Whole-grid VALUE datum (oracle/gen_golden_mpsa_whole_grid.py): the reference's pp.Mpsa was run on every cell of a
+    perturbed tetrahedral box of the configs[3] family -- heterogeneous Lame parameters, rollers, traction with a shear
+    component -- at 48 000 cells (144 000 unknowns; 269 s of discretization) and at 196 608 cells (589 824 unknowns,
+    stress with 196 M entries; 6 sub-problems, 1 272 s), with its own assemble_matrix_rhs and scipy BiCGStab to 1e-13,
+    and left block digests of stress, bound_stress, bound_displacement_cell, bound_displacement_face and of the
+    displacement field.  The device reproduces all of them."""
+    out = P.mpsa_whole_grid_check(lib, n)
     print("MPSA whole grid vs reference:", {k: v for k, v in out.items() if k != "reference"})
-    assert out["cells"] == 48000
+    assert out["cells"] == cells
     for k in P.MPSA_KEYS:
         assert max(out[k]) < 1e-10, (k, out[k])
     assert out["u_norm_rel_diff"] < 1e-10 and out["u_block_squares_worst_rel_diff"] < 1e-9, out
