@@ -1,5 +1,7 @@
 """GPU suite (-m gpu) for the MPSA path: gfx950 HIP library vs oracle, reference fixtures and
 exact solutions.  Nothing here reads /root/reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -146,7 +148,11 @@ def test_biot_partition_arguments_discretize_in_pieces(lib, name):
     P.biot_pieces_case(lib, name)
 
 
-@pytest.mark.parametrize("n, cells", [(20, 48000), (32, 196608)])
+_WHOLE = [(n, cells) for n, cells in ((20, 48000), (32, 196608), (44, 511104))
+          if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", f"mpsawhole_{n}.npz"))]
+
+
+@pytest.mark.parametrize("n, cells", _WHOLE)
 def test_all_four_matrices_and_the_displacement_field_on_a_whole_grid_against_the_reference(lib, n, cells):
     """Whole-grid VALUE datum (oracle/gen_golden_mpsa_whole_grid.py): the reference's pp.Mpsa was run on every cell of a
     perturbed tetrahedral box of the configs[3] family -- heterogeneous Lame parameters, rollers, traction with a shear
