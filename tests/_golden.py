@@ -20,7 +20,7 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "mpsasub_", "partial_", "tilted_", "tpfa_", "tpfaad_", "biot_", "subface_", "periodic_", "adflux_", "md_", "headline_", "persub_", "mpsawhole_"))]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "mpsasub_", "partial_", "tilted_", "tpfa_", "tpfaad_", "biot_", "subface_", "periodic_", "adflux_", "md_", "headline_", "persub_", "mpsawhole_", "biotwhole_"))]
 
 
 def mpsa_case_names():

@@ -2194,3 +2194,53 @@ def mpsa_whole_grid_check(lib, n: int = 16):
     ud, ur = bench.vector_digest(u, blocks), z["u_digest"]
     out["u_block_squares_worst_rel_diff"] = float(np.max(np.abs(ud[1] - ur[1]) / np.maximum(ur[1], 1e-300)))
     return out
+
+
+# ------------------------------------------------------------------------------------ Biot, whole-grid value datum
+def biot_whole_grid_alpha(nc: int):
+    """(3, 3, Nc) coupling tensor of oracle/gen_golden_biot_whole_grid.py: heterogeneous, anisotropic, symmetric."""
+    rng = np.random.default_rng(6)
+    a = np.zeros((3, 3, nc))
+    a[0, 0], a[1, 1], a[2, 2] = 0.6 + 0.4 * rng.random(nc), 0.5 + 0.5 * rng.random(nc), 0.7 + 0.3 * rng.random(nc)
+    a[0, 1] = a[1, 0] = 0.1 * rng.random(nc)
+    a[0, 2] = a[2, 0] = 0.05 * rng.random(nc)
+    a[1, 2] = a[2, 1] = 0.08 * rng.random(nc)
+    return a
+
+
+def biot_whole_grid_check(lib, n: int = 16):
+    """The five Biot coupling matrices (and stress / bound_stress) on the WHOLE grid against a run of the reference's
+    pp.Biot on it (tests/golden/biotwhole_<n>.npz): block digests of the values (bench.value_digest)."""
+    import json
+
+    import bench
+    from tests._golden import BIOT_KEYS
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"biotwhole_{n}.npz"))
+    info = json.loads(str(z["info"]))
+    g, mu, lam, is_dir, is_neu, _ = mpsa_whole_grid_problem(n)
+    assert g.num_cells == info["cells"]
+    bc = pa.BoundaryConditionVectorial(g)
+    bc.is_dir, bc.is_neu = is_dir.copy(), is_neu.copy()
+    al = type("A", (), {"values": biot_whole_grid_alpha(g.num_cells)})()
+    data = pa.initialize_data({}, "mechanics", {"fourth_order_tensor": pa.FourthOrderTensor(mu, lam), "bc": bc,
+                                               "mpsa_eta": 1.0 / 3.0, "scalar_vector_mappings": {"pressure": al}})
+    pa.Biot("mechanics", library=lib).discretize(g, data)
+    md = data[pa.DISCRETIZATION_MATRICES]["mechanics"]
+    rows = mpsa_stress_rows_that_count(pa.grid_to_raw(g), is_neu)
+    blocks = z["stress_digest"].shape[1]
+    out = {"cells": int(g.num_cells), "reference": info}
+
+    def worst(dev, ref):
+        scale = np.maximum(np.abs(ref[0]), 1e-300)
+        return [float(np.max(np.abs(dev[0] - ref[0]) / scale)),
+                float(np.max(np.abs(dev[1] - ref[1]) / np.maximum(np.abs(ref[1]), 1e-300))),
+                float(np.max(np.abs(dev[2] - ref[2]) / scale))]
+
+    for k in BIOT_KEYS:
+        M = md[k]["pressure"]
+        assert list(M.shape) == info["shapes"][k], (k, M.shape)
+        out[k] = worst(bench.value_digest(M, blocks, rows_mask=rows if k == "scalar_gradient" else None), z[k + "_digest"])
+    out["stress"] = worst(bench.value_digest(md["stress"], blocks, rows_mask=rows), z["stress_digest"])
+    out["bound_stress"] = worst(bench.value_digest(md["bound_stress"], blocks), z["bound_stress_digest"])
+    return out

@@ -187,3 +187,13 @@ def test_all_four_matrices_and_the_displacement_field_on_a_whole_grid_against_th
     for k in P.MPSA_KEYS:
         assert max(out[k]) < 1e-12, (k, out[k])
     assert out["u_norm_rel_diff"] < 1e-10 and out["u_block_squares_worst_rel_diff"] < 1e-9, out
+
+
+def test_biot_coupling_terms_on_a_whole_grid_against_the_reference(lib):
+    """Whole-grid VALUE datum for the Biot terms (oracle/gen_golden_biot_whole_grid.py): pp.Biot run on every cell of a
+    6 000-cell perturbed tetrahedral box (heterogeneous Lame parameters, anisotropic heterogeneous coupling tensor); the
+    kernels (host-emulation build) reproduce the block digests of the five coupling matrices and of stress / bound_stress."""
+    out = P.biot_whole_grid_check(lib, 10)
+    for k, v in out.items():
+        if isinstance(v, list):
+            assert max(v) < 1e-12, (k, v)

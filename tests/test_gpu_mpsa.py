@@ -166,3 +166,16 @@ def test_all_four_matrices_and_the_displacement_field_on_a_whole_grid_against_th
     for k in P.MPSA_KEYS:
         assert max(out[k]) < 1e-10, (k, out[k])
     assert out["u_norm_rel_diff"] < 1e-10 and out["u_block_squares_worst_rel_diff"] < 1e-9, out
+
+
+def test_biot_coupling_terms_on_a_whole_grid_against_the_reference(lib):
+    """Whole-grid VALUE datum for the Biot terms (oracle/gen_golden_biot_whole_grid.py): the reference's pp.Biot run on
+    every one of the 48 000 cells of a perturbed tetrahedral box (heterogeneous Lame parameters, anisotropic heterogeneous
+    coupling tensor) left block digests of scalar_gradient, displacement_divergence, boundary_displacement_divergence,
+    mpsa_consistency, bound_displacement_pressure and of stress / bound_stress; the device reproduces all of them."""
+    out = P.biot_whole_grid_check(lib, 20)
+    print("Biot whole grid vs reference:", {k: v for k, v in out.items() if k != "reference"})
+    assert out["cells"] == 48000
+    for k, v in out.items():
+        if isinstance(v, list):
+            assert max(v) < 1e-10, (k, v)
