@@ -476,21 +476,33 @@ N_BLOCKS = 1024
 def value_digest(M, n_blocks: int = N_BLOCKS, rows_mask=None):
     """Per block of consecutive rows (n_blocks blocks) of a CSR matrix: sum |a|, sum a^2, and sum a * w(column) with
     w(c) = 0.5 + frac(c * golden ratio) -- fixed weights in [0.5, 1.5) that do not annihilate rows summing to zero.
-    The same function is applied to the device's matrix by bench.whole_grid_check.  rows_mask: rows that count."""
+    The same function makes the reference's fixtures (oracle/gen_golden_headline_pattern.py, gen_golden_mpsa_whole_grid.py,
+    gen_golden_biot_whole_grid.py) and digests the device's matrices.  rows_mask: rows that count.  Row chunks of
+    2^18 (a 670 M-entry matrix passes with a few hundred MB of work space)."""
     import scipy.sparse as sps
 
     M = sps.csr_matrix(M)
     n = M.shape[0]
     rows_per = -(-n // n_blocks)
-    row_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(M.indptr))
-    blk = row_of // rows_per
-    w = 0.5 + np.mod(M.indices.astype(np.float64) * 0.6180339887498949, 1.0)
-    a = M.data
-    if rows_mask is not None:  # (rows left out: the Neumann boundary rows of flux, whose true entries are all zero)
-        a = np.where(np.asarray(rows_mask, bool)[row_of], a, 0.0)
-    return np.stack([np.bincount(blk, weights=np.abs(a), minlength=n_blocks),
-                     np.bincount(blk, weights=a * a, minlength=n_blocks),
-                     np.bincount(blk, weights=a * w, minlength=n_blocks)])
+    out = np.zeros((3, n_blocks))
+    indptr = np.asarray(M.indptr, dtype=np.int64)
+    mask = None if rows_mask is None else np.asarray(rows_mask, bool)
+    step = 1 << 18
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        e0, e1 = int(indptr[r0]), int(indptr[r1])
+        if e1 == e0:
+            continue
+        row_of = np.repeat(np.arange(r0, r1, dtype=np.int64), np.diff(indptr[r0:r1 + 1]))
+        a = np.asarray(M.data[e0:e1], dtype=float)
+        if mask is not None:  # (rows left out: e.g. the Neumann boundary rows of flux, whose true entries are all zero)
+            a = np.where(mask[row_of], a, 0.0)
+        w = 0.5 + np.mod(M.indices[e0:e1].astype(np.float64) * 0.6180339887498949, 1.0)
+        blk = row_of // rows_per
+        out[0] += np.bincount(blk, weights=np.abs(a), minlength=n_blocks)
+        out[1] += np.bincount(blk, weights=a * a, minlength=n_blocks)
+        out[2] += np.bincount(blk, weights=a * w, minlength=n_blocks)
+    return out
 
 
 def vector_digest(x, n_blocks: int = N_BLOCKS):
@@ -526,6 +538,15 @@ def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_patt
         x, info = ctx.solve("bicgstab", rtol=rtol, maxit=20000, raise_on_fail=False, precond=precond)
         F = ctx.matrix(pa._lib.MAT_FLUX)
         BF = ctx.matrix(pa._lib.MAT_BOUND_FLUX) if "flux_value_digest" in z.files else None
+        more = {}
+        if "vector_source_value_digest" in z.files:  # (all six matrices: digested one at a time, 8 GB each for the largest)
+            for name, which, msk in (("bound_pressure_cell", pa._lib.MAT_BOUND_PRESSURE_CELL, None),
+                                     ("bound_pressure_face", pa._lib.MAT_BOUND_PRESSURE_FACE, None),
+                                     ("vector_source", pa._lib.MAT_VECTOR_SOURCE, ~neu),
+                                     ("bound_pressure_vector_source", pa._lib.MAT_BOUND_PRESSURE_VECTOR_SOURCE, None)):
+                Mx = ctx.matrix(which)
+                more[name] = value_digest(Mx, z[name + "_value_digest"].shape[1], rows_mask=msk)
+                del Mx
         nnz_sys = int(ctx.matrix_info(pa._lib.MAT_SYSTEM)[2])
     finally:
         ctx.close()
@@ -560,6 +581,7 @@ def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_patt
             "blocks": int(z["flux_value_digest"].shape[1]),
             "flux_worst_rel_diff_abs_sq_weighted": worst(value_digest(F, rows_mask=~neu), z["flux_value_digest"]),
             "bound_flux_worst_rel_diff_abs_sq_weighted": worst(value_digest(BF), z["bound_flux_value_digest"]),
+            **{k + "_worst_rel_diff_abs_sq_weighted": worst(v, z[k + "_value_digest"]) for k, v in more.items()},
             "pressure_norm_reference": float(z["pressure_norm"][0]),
             "pressure_norm_rel_diff": float(abs(np.linalg.norm(x) - z["pressure_norm"][0]) / z["pressure_norm"][0]),
             "reference_solve": json.loads(str(z["solve"])),

@@ -109,6 +109,12 @@ def main(n_side: int = 69, num_sub: int = 12, out_dir: str | None = None):
     out = {
         "flux_value_digest": value_digest(F, rows_mask=~neumann_row),
         "bound_flux_value_digest": value_digest(md["bound_flux"]),
+        # (the other four matrices of the discretization: pressure traces and the vector-source terms; the rows of
+        # vector_source at Neumann boundary faces are cancellation noise like those of flux)
+        "bound_pressure_cell_value_digest": value_digest(md["bound_pressure_cell"]),
+        "bound_pressure_face_value_digest": value_digest(md["bound_pressure_face"]),
+        "vector_source_value_digest": value_digest(md["vector_source"], rows_mask=~neumann_row),
+        "bound_pressure_vector_source_value_digest": value_digest(md["bound_pressure_vector_source"]),
         "pressure_digest": vector_digest(p),
         "pressure_norm": np.array([float(np.linalg.norm(p))]),
         "solve": np.array(json.dumps({"iterations": its[0], "flag": int(flag), "true_rel_residual": res,

@@ -279,4 +279,6 @@ def test_whole_grid_datum_machinery_on_a_small_grid(tmp_path):
     assert out["pattern_row_lengths_equal"] and headline_digest(indptr, indices, rows) == ref_digest
     v = out["values_vs_reference"]
     assert max(v["flux_worst_rel_diff_abs_sq_weighted"]) < 1e-12 and max(v["bound_flux_worst_rel_diff_abs_sq_weighted"]) < 1e-12
+    for k in ("bound_pressure_cell", "bound_pressure_face", "vector_source", "bound_pressure_vector_source"):
+        assert max(v[k + "_worst_rel_diff_abs_sq_weighted"]) < 1e-12, (k, v[k + "_worst_rel_diff_abs_sq_weighted"])
     assert v["pressure_norm_rel_diff"] < 1e-10 and v["pressure_block_squares_worst_rel_diff"] < 1e-9
