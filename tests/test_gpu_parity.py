@@ -401,6 +401,11 @@ def test_whole_headline_grid_pattern_against_the_reference_run_on_the_whole_grid
     assert max(v["flux_worst_rel_diff_abs_sq_weighted"]) < 1e-10, v
     assert max(v["bound_flux_worst_rel_diff_abs_sq_weighted"]) < 1e-10, v
     assert v["pressure_norm_rel_diff"] < 1e-10, v
+    # (the other four matrices, when the fixture carries them: pressure traces and the two vector-source matrices,
+    # 672 M entries each)
+    for k in ("bound_pressure_cell", "bound_pressure_face", "vector_source", "bound_pressure_vector_source"):
+        if k + "_worst_rel_diff_abs_sq_weighted" in v:
+            assert max(v[k + "_worst_rel_diff_abs_sq_weighted"]) < 1e-10, (k, v[k + "_worst_rel_diff_abs_sq_weighted"])
 
 
 def test_config_c2_all_matrices_on_patches(lib):
