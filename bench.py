@@ -915,7 +915,8 @@ def main():
     # all rebuilt): the cold figure beside the headline
     cold = None
     if not args.no_cold:
-        off = {"PFV_AMG_REUSE_REBUILT": "0", "PFV_WIN_REUSE": "0", "PFV_AMG_FILTER_LAYOUT_REUSE": "0", "PFV_AMG_SIZES_REUSE": "0"}
+        off = {"PFV_AMG_REUSE_REBUILT": "0", "PFV_WIN_REUSE": "0", "PFV_AMG_FILTER_LAYOUT_REUSE": "0", "PFV_AMG_SIZES_REUSE": "0",
+               "PFV_SYMB_REUSE": "0"}
         saved = {k: os.environ.get(k) for k in off}
         os.environ.update(off)
         try:
@@ -937,6 +938,7 @@ def main():
                     "iterations": int(infoc["iterations"]) if isinstance(infoc, dict) else None,
                     "amg_setup_ms": stc["amg_setup_ms"], "kept": {"amg_aggregate_maps": int(stc.get("amg_maps_reused", 0)),
                                                                    "spmv_windows": int(stc.get("win_reused", 0)),
+                                                                   "csr_patterns": int(stc.get("symbolic_reused", 0)),
                                                                    "amg_filter_layout": int(stc.get("amg_filter_layout", 0))},
                     "switches": off}
         finally:
@@ -945,6 +947,7 @@ def main():
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+        step()             # (patterns built under PFV_SYMB_REUSE=0 carry no key: this step rebuilds them WITH one)
         x, info = step()   # (back to the default step: the diagnostics below look at its state)
         ctx.sync()
         st = ctx.stats()
@@ -1175,6 +1178,8 @@ def main():
                        "self_launched": os.environ.get("PFV_BENCH_SELF_LAUNCHED") == "1",
                        "pattern_reuse": {"amg_aggregate_maps_kept": int(st.get("amg_maps_reused", 0)),
                                          "spmv_windows_kept": int(st.get("win_reused", 0)),
+                                         "csr_patterns_kept": int(st.get("symbolic_reused", 0)),
+                                         "symbolic_ms": st.get("symbolic_ms"),
                                          "amg_filter_layout": int(st.get("amg_filter_layout", 0)),
                                          "value_dependent_note": "amg_filter_layout 1 = the strength filter of the AMG setup wrote "
                                                                  "into the row layout of the previous step's filtering instead of "
@@ -1183,10 +1188,13 @@ def main():
                                                                  "every step (the default) it stays 0; the filtered windows and the "
                                                                  "Galerkin sizes are kept only on an equal digest of the FILTERED "
                                                                  "index arrays, which moving values do not reproduce either",
-                                         "note": "every step rebuilds the sub-cell topology, all CSR patterns, all values, the "
-                                                 "strength filter, the Galerkin products and the solve, on a permeability field "
-                                                 "that changes from step to step.  Kept when the symbolic phase proves A's new "
-                                                 "pattern equal (sizes + 64-bit digest of the index arrays): the SpMV windows of A "
+                                         "note": "every step rebuilds the sub-cell topology, all values, the strength filter, the "
+                                                 "Galerkin products and the solve, on a permeability field that changes from step "
+                                                 "to step.  Kept when the REBUILT topology is proved equal (sizes + 64-bit digest "
+                                                 "of every array the symbolic phase reads) to the one they were built from: the "
+                                                 "CSR patterns of the six matrices and of A, the column maps and face records "
+                                                 "(csr_patterns_kept; symbolic_ms then is the time of the proof; VERDICT r5 item 6); "
+                                                 "kept on an equal digest of A's index arrays: the SpMV windows of A "
                                                  "(a function of the pattern alone) and the pairwise aggregate maps of the AMG "
                                                  "levels -- the latter follow the strength of connection of the VALUES they were "
                                                  "built from, i.e. the cycle coarsens along the previous step's field (what a "

@@ -128,6 +128,17 @@ typedef struct {
   int64_t node_redo;              /* interaction regions the first launch of the last discretization handed to the
                                      pivoted full body: those whose unpivoted elimination failed its a-posteriori check
                                      (PFV_NODE_GJ=5), or whose condition asked for refinement in a lean launch */
+  int64_t symbolic_reused;        /* 1: the last discretize with PFV_DISCR_REBUILD_TOPOLOGY rebuilt the topology, proved it
+                                     equal (64-bit digest of what the symbolic phase reads + sizes) to the one the CSR
+                                     patterns on the handle were built from, and kept them; symbolic_ms then is the time of
+                                     the proof.  0: the patterns were rebuilt (first call, new grid, PFV_SYMB_REUSE=0) */
+  int64_t amg_stale_rematches;    /* times a solve on KEPT aggregate maps needed more than 1.3 x the iterations of the first
+                                     solve after their matching (same tolerance and method): the maps were dropped and the
+                                     next setup matched again */
+  int64_t mpsa_contrast_regions;  /* MPSA: interaction regions of the last discretization whose sub-cells' stiffness scales
+                                     differ by more than PFV_MPSA_CONTRAST_LIMIT (1e6) -- the regions that were assembled and
+                                     eliminated in double-double arithmetic (mpsa_dd.inc) */
+  double mpsa_max_contrast;       /* MPSA: the largest such ratio over all interaction regions (1: homogeneous) */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);

@@ -136,6 +136,9 @@ class Biot(Mpsa):
             if e.status == 2:
                 raise AssertionError(e.message) from e
             raise
+        from .mpsa import _note_contrast_regions
+
+        _note_contrast_regions(ctx)
         for name, which in _MECH_KEYS:
             md[name] = ctx.matrix(which)
         for name, term in _TERMS:

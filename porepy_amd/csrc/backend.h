@@ -14,6 +14,7 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -43,7 +44,7 @@
 // argument is substituted)
 #define PFV_LAUNCH(kernel, ...)                  \
   do {                                           \
-    ++::pfv::launch_counter();                   \
+    ::pfv::launch_counter().fetch_add(1, std::memory_order_relaxed); \
     hipLaunchKernelGGL((kernel), __VA_ARGS__);   \
   } while (0)
 #endif
@@ -60,8 +61,10 @@ struct Error : std::runtime_error {
 constexpr int kWave = 64;
 
 // kernel dispatches issued by this library (every launch site goes through PFV_LAUNCH): pfv_stats.solve_launches
-inline long long& launch_counter() {
-  static long long c = 0;
+// (relaxed atomic: handles on different threads, or a discretization on the second stream beside a solve, all count
+// here; differences of it are statistics, not synchronisation)
+inline std::atomic<long long>& launch_counter() {
+  static std::atomic<long long> c{0};
   return c;
 }
 
@@ -296,11 +299,23 @@ struct Buf {
   // step: 10 ms per step over the first steps of a run, until every buffer had seen its largest size).
   T* ensure(size_t n) {
     if (n > cap) {
-      const size_t want = cap > 0 ? std::max(n, cap + cap / 8) : n;
+      // (the head room is bounded -- 64 MiB: the sizes that move are those of the solver's level structures, not the
+      // multi-GB value arrays of the discretization -- and never the reason for a failure: if the larger request does
+      // not fit, the exact one is tried before giving up)
+      const size_t room = std::min(cap / 8, (size_t(64) << 20) / sizeof(T));
+      size_t want = cap > 0 ? std::max(n, cap + room) : n;
       be_free(p);
       p = nullptr;
       cap = 0;
-      p = static_cast<T*>(be_malloc(want * sizeof(T)));
+      if (want > n) {
+        try {
+          p = static_cast<T*>(be_malloc(want * sizeof(T)));
+        } catch (const Error&) {
+          p = nullptr;
+          want = n;
+        }
+      }
+      if (!p) p = static_cast<T*>(be_malloc(want * sizeof(T)));
       cap = want;
     }
     return p;

@@ -263,6 +263,8 @@ struct pfv_ctx_impl {
   unsigned long long win_sys_checksum = 0; // ... of the pattern win_sys was built for (0: unknown)
   unsigned long long win_rows_checksum = 0; // ... of the pattern whose leading win_rows_n rows win_rows covers
   unsigned long long symbolic_epoch = 0;  // bumped by every symbolic phase: saved AMG aggregates die with it
+  unsigned long long topo_key = 0;   // topology_digest of the topology on the handle (0: not taken)
+  unsigned long long symb_key = 0;   // ... of the topology the symbolic outputs on the handle were built from (0: none / replaced)
   std::unique_ptr<BlockPc> block_pc;  // pfv_set_block_preconditioner
   std::unique_ptr<Amg> amg_block;    // pfv_amg_setup: hierarchy of the leading block (sharded solves)
   CsrPattern pat_block;
@@ -277,6 +279,10 @@ struct pfv_ctx_impl {
   std::function<void(stream_t, int64_t)> node_redo_launch;  // ... and the launch that takes them (set by launch_node_kernel)
   int64_t stats_node_redo = 0;
   Buf<int32_t> mpsa_redo;            // nodes the lean MPSA launches hand to the full body (mpsa.inc)
+  Buf<int32_t> mpsa_cell_exp;        // binary exponent of every cell's stiffness scale (mpsa.inc: mpsa_contrast_scan)
+  Buf<uint8_t> mpsa_wide_flag;       // [nn] 1: interaction region of high stiffness contrast -> double-double body
+  Buf<int32_t> mpsa_wide_list;       // the flagged nodes (order of arrival: every region writes its own rows only)
+  Buf<int32_t> mpsa_wide_stat;       // [0] their number, [1] largest exponent difference over all regions
   int64_t stats_mpsa_redo = 0;
   Buf<double> red5;                  // block partials of the sharded BiCGStab's five merged sums
   double* shard_work = nullptr;      // [2 * shard_nloc + 8]: the two SpMV inputs (owned + halo entries), reduction scratch

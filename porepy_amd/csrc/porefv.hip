@@ -17,6 +17,7 @@ static int rccl_exchange_halo(void* user, double* d_x, void* stream);  // rccl_h
 #include "mpfa_numeric.inc"
 #include "linalg.inc"
 #include "reorder.inc"
+#include "dd.h"
 #include "mpsa.inc"
 #include "tpfa.inc"
 #include "biot.inc"
@@ -268,6 +269,7 @@ pfv_status pfv_set_grid(pfv_ctx* h, int nd, int64_t nc, int64_t nf, int64_t nn, 
     h->perm_for_val = nullptr;
     h->win_for = h->win_rows_for = nullptr;
     h->have_topology = h->have_symbolic = h->have_numeric = h->have_system = false;
+    h->topo_key = h->symb_key = 0;
     h->win_sys_prebuilt = h->win_rows_prebuilt = false;
     h->biot_rows_complete = false;
     h->rows_complete = false;
@@ -353,6 +355,32 @@ pfv_status pfv_mpfa_set_subface_bc(pfv_ctx* h, const uint8_t* bc_flags_sub, cons
   });
 }
 
+namespace {
+// A rebuilt topology (PFV_DISCR_REBUILD_TOPOLOGY, the timed step of bench.py) against the symbolic outputs the handle
+// still holds: the patterns of the six matrices and of A, the column -> pair maps and the face records are functions of
+// the topology alone.  When the digest of the topology just built equals the one they were built from (topology.inc:
+// topology_digest; sizes are part of it) they are kept: nothing build_symbolic would write differs from what is there.
+// The topology itself is ALWAYS rebuilt -- that is what the flag asks for, and what the digest is taken of; a miss (new
+// grid, other boundary, first call) runs the symbolic phase as before.  PFV_SYMB_REUSE=0: never keep (the cold step).
+// Ref: the phase this stands for is SubcellTopology + the index work of the SpGEMM chain, _fvutils.py:51-172.
+bool symbolic_outputs_still_valid(pfv_ctx* h) {
+  h->stats.symbolic_reused = 0;
+  if (pfv::env_int("PFV_SYMB_REUSE", 1) == 0) {
+    h->topo_key = 0;
+    return false;
+  }
+  h->topo_key = pfv::topology_digest(*h);
+  const bool keep = h->have_symbolic && !h->tpfa_mode && h->symb_key != 0 && h->symb_key == h->topo_key &&
+                    h->pat_flux.nrows == h->nf && h->pat_A.nrows == h->nc;
+  if (keep) {
+    // what build_symbolic's prologue does for the VALUES: they belong to the previous discretization
+    for (int m = PFV_MAT_FLUX; m <= PFV_MAT_SYSTEM; ++m) h->filled[m] = false;
+    h->stats.symbolic_reused = 1;
+  }
+  return keep;
+}
+}  // namespace
+
 pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
   return guarded(h, [&] {
     require(h->have_grid && h->have_params, "grid and parameters must be set before discretize");
@@ -366,6 +394,12 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
       tm.start(s);
       pfv::build_topology(*h);
       h->stats.topology_ms = tm.stop(s);
+      tm.start(s);
+      const bool keep_symbolic = symbolic_outputs_still_valid(h);
+      if (keep_symbolic) {
+        h->stats.symbolic_ms = tm.stop(s);  // (the digest and its read-back)
+        node_done = false;                  // the interaction-region kernel has the device to itself, below
+      } else {
 #ifndef PFV_EMULATE
       // The symbolic phase (CSR patterns) and the interaction-region kernel (local inverses) both
       // depend on the sub-cell topology only, and both are bound by latency at low occupancy, not by
@@ -400,6 +434,7 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
       }
       h->tpfa_mode = false;
       h->have_sub_symbolic = h->have_mpsa_sub_symbolic = false;
+      }  // !keep_symbolic
     }
     if (!node_done) {
       tm.start(s);
@@ -506,6 +541,7 @@ pfv_status pfv_tpfa_discretize(pfv_ctx* h, int vector_source_dim) {
     pfv::Timer tm;
     tm.start(s);
     h->have_symbolic = false;  // the MPFA patterns (if any) are replaced
+    h->symb_key = 0;
     h->rows_complete = false;
     for (int m = PFV_MAT_FLUX; m <= PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE; ++m) h->filled[m] = false;
     h->filled[PFV_MAT_SYSTEM] = false;
@@ -940,12 +976,21 @@ pfv_status pfv_mpsa_discretize(pfv_ctx* h, uint32_t flags) {
       pfv::build_topology(*h);
       h->stats.topology_ms = tm.stop(s);
       tm.start(s);
+      // (a rebuilt topology that is proved equal to the one the patterns were built from keeps them -- and with them
+      // their block expansions of mpsa_symbolic, functions of those patterns alone; see symbolic_outputs_still_valid)
+      const bool had_mpsa_symbolic = h->have_mpsa_symbolic;
+      if (symbolic_outputs_still_valid(h)) {
+        h->stats.symbolic_ms = tm.stop(s);
+        h->have_mpsa_symbolic = had_mpsa_symbolic;
+        h->have_numeric = h->have_system = false;
+      } else {
       pfv::build_symbolic(*h);
       h->stats.symbolic_ms = tm.stop(s);
       h->tpfa_mode = false;
       h->have_mpsa_symbolic = false;
       h->have_sub_symbolic = h->have_mpsa_sub_symbolic = false;
       h->have_numeric = h->have_system = false;
+      }
     }
     if (!h->have_mpsa_symbolic) {
       tm.start(s);
@@ -1640,7 +1685,7 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
     }
     pfv::Precond M;
     const pfv::Precond* Mp = nullptr;
-    const long long launches_before_setup = pfv::launch_counter();
+    const long long launches_before_setup = pfv::launch_counter().load(std::memory_order_relaxed);
     if (h->precond == PFV_PRECOND_AMG) {
       if (!h->amg) h->amg = std::make_unique<pfv::Amg>();
       if (!h->amg->valid || h->amg_for_val != sys.val) {
@@ -1651,6 +1696,7 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
         h->stats.amg_levels = (int64_t)h->amg->nlev;
         h->stats.amg_coarsest_rows = h->amg->lev[h->amg->nlev - 1]->n;
         h->stats.amg_maps_reused = h->amg->reused ? 1 : 0;
+        h->stats.amg_stale_rematches = h->amg->stale_rematches;
         h->stats.amg_level0_nnz = h->amg->lev[0]->P->nnz;
         h->stats.amg_filter_theta = h->amg->filter_level0 ? h->amg->filter_theta : 0.0;
       }
@@ -1669,12 +1715,13 @@ pfv_status pfv_solve(pfv_ctx* h, int method, double rtol, int maxit, int restart
       M.diag = sys.diag;
       Mp = &M;
     }
-    const long long launches_before_loop = pfv::launch_counter();
+    const long long launches_before_loop = pfv::launch_counter().load(std::memory_order_relaxed);
     h->stats.amg_setup_launches = (int64_t)(launches_before_loop - launches_before_setup);
     res = method == PFV_SOLVE_GMRES
               ? pfv::gmres_solve(*h, sys, rtol, maxit, restart, dxs, x0 == nullptr, Mp)
               : pfv::krylov_solve(*h, sys, method, rtol, maxit, dxs, x0 == nullptr, Mp);
-    h->stats.solve_launches = (int64_t)(pfv::launch_counter() - launches_before_loop);
+    if (M.amg && x0 == nullptr) h->amg->note_iterations(res.iterations, rtol, method, res.converged);
+    h->stats.solve_launches = (int64_t)(pfv::launch_counter().load(std::memory_order_relaxed) - launches_before_loop);
     if (permuted) pfv::permute_vector(*h, (int64_t)n, h->active_bs, dxs, dx, false);
     h->stats.solve_ms = tm.stop(s);
     if (h->vectors_on_device) pfv::be_d2d(x, dx, n * sizeof(double), s); else be_d2h(x, dx, n * sizeof(double), s);
@@ -1794,6 +1841,7 @@ pfv_status pfv_solve_sharded(pfv_ctx* h, int method, double rtol, int maxit, int
       throw;
     }
     h->shard = nullptr;
+    if (M.amg) h->amg_block->note_iterations(res.iterations, rtol, method, res.converged);
     h->stats.solve_ms = tm.stop(s);
   });
   if (info) {

@@ -26,6 +26,28 @@ _KEYS = (
 )
 
 
+
+def _note_contrast_regions(ctx) -> None:
+    """Say what the library did about interaction regions whose sub-cells' stiffnesses are more than 1e6 apart
+    (``pfv_stats.mpsa_contrast_regions`` / ``mpsa_max_contrast``, csrc/mpsa.inc: mpsa_contrast_scan): assembled and
+    eliminated in double-double arithmetic (the default; equal to the reference's result to 1e-10 and better) --
+    or, with ``PFV_MPSA_DD=0``, left to the FP64 body, which is then only within ~eps x contrast of the reference."""
+    import logging
+    import os
+
+    st = ctx.stats()
+    n = int(st.get("mpsa_contrast_regions", 0))
+    if n <= 0:
+        return
+    log = logging.getLogger("porepy_amd")
+    if os.environ.get("PFV_MPSA_DD", "1") == "0":
+        log.warning("Mpsa: %d interaction regions with stiffness contrasts up to %.1e between cells sharing a node and "
+                    "PFV_MPSA_DD=0: the FP64 condensed systems agree with the reference only to ~1e-16 x contrast there",
+                    n, st.get("mpsa_max_contrast", float("nan")))
+    else:
+        log.info("Mpsa: %d interaction regions with stiffness contrasts up to %.1e between cells sharing a node were "
+                 "assembled and eliminated in double-double arithmetic", n, st.get("mpsa_max_contrast", float("nan")))
+
 class Mpsa:
     def __init__(self, keyword: str, device: int = 0, library=None):
         self.keyword = keyword
@@ -156,6 +178,7 @@ class Mpsa:
             if e.status == 2:
                 raise AssertionError(e.message) from e
             raise
+        _note_contrast_regions(ctx)
         for name, which in _KEYS:
             new = ctx.matrix(which, rows=rows)
             if order is not None and not np.array_equal(order, np.arange(order.size)):

@@ -20,7 +20,7 @@ ALL_KEYS = (
 
 def case_names():
     names = [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))]
-    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "mpsasub_", "partial_", "tilted_", "tpfa_", "tpfaad_", "biot_", "subface_", "periodic_", "adflux_", "md_", "headline_", "persub_", "mpsawhole_", "biotwhole_"))]
+    return [n for n in names if n != "scalar_known_answers" and not n.startswith(("mpsa_", "mpsapartial_", "mpsasub_", "partial_", "tilted_", "tpfa_", "tpfaad_", "biot_", "subface_", "periodic_", "adflux_", "md_", "headline_", "persub_", "mpsawhole_", "biotwhole_", "mpsacontrast_"))]
 
 
 def mpsa_case_names():
@@ -29,6 +29,32 @@ def mpsa_case_names():
 
 
 MPSA_KEYS = ("stress", "bound_stress", "bound_displacement_cell", "bound_displacement_face")
+
+
+def mpsa_contrast_case_names():
+    return [os.path.basename(p)[:-4] for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, "mpsacontrast_*.npz")))]
+
+
+class MpsaContrastCase:
+    """MPSA fixture with Lame parameters of neighbouring cells apart by 1e8 ... 1e12 (oracle/gen_golden_mpsa_contrast.py):
+    the matrices of the reference's ``pp.Mpsa``, the matrices of the reference's own local systems inverted in 60-digit
+    arithmetic ("exact"), and how far the former are from the latter."""
+
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
+        self.grid["dim"] = int(self.grid["dim"])
+        self.grid["name"] = str(self.grid["name"])
+        self.bc = {"is_dir": z["bc_is_dir"], "is_neu": z["bc_is_neu"]}
+        self.stiffness = z["stiffness"]
+        self.decades = float(z["decades"])
+        self.ref, self.exact, self.ref_off_exact = {}, {}, {}
+        for k in MPSA_KEYS:
+            for tag, dst in (("ref", self.ref), ("exact", self.exact)):
+                shape = tuple(int(v) for v in z[f"{tag}_{k}_shape"])
+                dst[k] = sps.csr_matrix((z[f"{tag}_{k}_data"], z[f"{tag}_{k}_indices"], z[f"{tag}_{k}_indptr"]), shape=shape)
+            self.ref_off_exact[k] = float(z[f"ref_off_exact_{k}"])
 
 
 def mpsa_subface_case_names():

@@ -731,9 +731,23 @@ def amg_preconditioner(lib, g, seed=2, hetero_sigma=0.5):
     xf, i_f = d.solve(g, data, source=src, method="bicgstab", rtol=1e-12, precond="amg")
     assert d.context(g).stats()["amg_maps_reused"] == 1
     assert np.array_equal(xf, xr) and i_f["iterations"] == ir["iterations"]  # same aggregates, same values: same bits
+    # (round 6: a rebuilt topology that is proved unchanged keeps the symbolic phase's outputs -- the SAME symbolic phase,
+    # so the maps survive even with PFV_AMG_REUSE_REBUILT=0 ...)
     os.environ["PFV_AMG_REUSE_REBUILT"] = "0"
     try:
         d.discretize(g, data)
+        assert d.context(g).stats()["symbolic_reused"] == 1
+        d.assemble_matrix_rhs(g, data)
+        xf, i_f = d.solve(g, data, source=src, method="bicgstab", rtol=1e-12, precond="amg")
+        assert d.context(g).stats()["amg_maps_reused"] == 1
+        assert np.array_equal(xf, xr)
+        # (... and only a symbolic phase that really ran again, PFV_SYMB_REUSE=0, makes them a different epoch's)
+        os.environ["PFV_SYMB_REUSE"] = "0"
+        try:
+            d.discretize(g, data)
+        finally:
+            del os.environ["PFV_SYMB_REUSE"]
+        assert d.context(g).stats()["symbolic_reused"] == 0
         d.assemble_matrix_rhs(g, data)
         xf, i_f = d.solve(g, data, source=src, method="bicgstab", rtol=1e-12, precond="amg")
         assert d.context(g).stats()["amg_maps_reused"] == 0
@@ -2244,3 +2258,159 @@ def biot_whole_grid_check(lib, n: int = 16):
     out["stress"] = worst(bench.value_digest(md["stress"], blocks, rows_mask=rows), z["stress_digest"])
     out["bound_stress"] = worst(bench.value_digest(md["bound_stress"], blocks), z["bound_stress_digest"])
     return out
+
+
+def symbolic_reuse_on_rebuilt_topology(lib, n=4):
+    """A discretization with ``rebuild_topology=True`` always rebuilds the sub-cell topology; the CSR patterns, column
+    maps and face records are kept when the rebuilt topology is PROVED equal (digest + sizes) to the one they were built
+    from (``pfv_stats.symbolic_reused``), and rebuilt on every miss: another grid, another boundary, ``PFV_SYMB_REUSE=0``.
+    Kept or rebuilt, the matrices must be the same bits (the pattern) and the same values as a cold handle's."""
+    M = pa._lib
+    keys = (M.MAT_FLUX, M.MAT_BOUND_FLUX, M.MAT_BOUND_PRESSURE_CELL, M.MAT_BOUND_PRESSURE_FACE, M.MAT_VECTOR_SOURCE,
+            M.MAT_BOUND_PRESSURE_VECTOR_SOURCE)
+
+    def problem(nn, seed, all_dir=False):
+        g = pa.StructuredTetrahedralGrid([nn, nn, nn], [1.0, 1.0, 1.0])
+        g.compute_geometry()
+        g = pa.perturb_interior_nodes(g, 0.03)
+        rng = np.random.default_rng(seed)
+        sc = np.exp(0.7 * rng.standard_normal(g.num_cells))
+        K = pa.SecondOrderTensor(kxx=sc, kyy=3 * sc, kzz=0.5 * sc, kxy=0.2 * sc, kyz=0.1 * sc)
+        bf = g.get_all_boundary_faces()
+        flags = np.zeros(g.num_faces, dtype=np.uint8)
+        flags[bf] = 2
+        dirf = bf if all_dir else bf[g.face_centers[0, bf] < 1e-9]
+        flags[dirf] = 1
+        return pa.grid_to_raw(g), np.ascontiguousarray(K.values), flags
+
+    def mats(ctx):
+        out = [ctx.matrix(k) for k in keys]
+        return out
+
+    def same(a, b, exact_values):
+        for x, y in zip(a, b):
+            assert np.array_equal(x.indptr, y.indptr) and np.array_equal(x.indices, y.indices)
+            if exact_values:
+                assert np.array_equal(x.data, y.data)
+
+    raw, K1, flags = problem(n, 1)
+    _, K2, _ = problem(n, 2)
+    cold = pa.Context(0, lib)
+    cold.set_grid(raw)
+    cold.set_params(K2, flags, None, 1.0 / 3.0)
+    cold.discretize()
+    ref2 = mats(cold)
+    assert cold.stats()["symbolic_reused"] == 0
+
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(raw)
+    ctx.set_params(K1, flags, None, 1.0 / 3.0)
+    ctx.discretize(rebuild_topology=True)
+    assert ctx.stats()["symbolic_reused"] == 0          # first call: nothing to keep
+    ctx.set_params(K2, flags, None, 1.0 / 3.0)          # new values, same grid
+    ctx.discretize(rebuild_topology=True)
+    st = ctx.stats()
+    assert st["symbolic_reused"] == 1, st
+    same(mats(ctx), ref2, exact_values=True)            # kept patterns, the cold handle's bits
+    ctx.assemble(np.zeros(raw["face_centers"].shape[1]), None, raw["cell_volumes"])
+    cold.assemble(np.zeros(raw["face_centers"].shape[1]), None, raw["cell_volumes"])
+    A1, A2 = ctx.matrix(M.MAT_SYSTEM), cold.matrix(M.MAT_SYSTEM)
+    assert np.array_equal(A1.indices, A2.indices) and np.array_equal(A1.data, A2.data)
+
+    # other condition TYPES on the same boundary: the patterns do not depend on them -> still kept
+    _, _, flags_d = problem(n, 1, all_dir=True)
+    ctx.set_params(K2, flags_d, None, 1.0 / 3.0)
+    ctx.discretize(rebuild_topology=True)
+    assert ctx.stats()["symbolic_reused"] == 1
+    cold_d = pa.Context(0, lib)
+    cold_d.set_grid(raw)
+    cold_d.set_params(K2, flags_d, None, 1.0 / 3.0)
+    cold_d.discretize()
+    same(mats(ctx), mats(cold_d), exact_values=True)
+
+    # the switch: never keep
+    os.environ["PFV_SYMB_REUSE"] = "0"
+    try:
+        ctx.discretize(rebuild_topology=True)
+        assert ctx.stats()["symbolic_reused"] == 0
+        same(mats(ctx), mats(cold_d), exact_values=True)
+    finally:
+        del os.environ["PFV_SYMB_REUSE"]
+    ctx.discretize(rebuild_topology=True)
+    assert ctx.stats()["symbolic_reused"] == 0          # (patterns built under the switch carry no key: rebuilt once more)
+    ctx.discretize(rebuild_topology=True)
+    assert ctx.stats()["symbolic_reused"] == 1
+    same(mats(ctx), mats(cold_d), exact_values=True)
+
+    # another grid on the same handle: a miss, and the right matrices
+    raw3, K3, flags3 = problem(n + 1, 3)
+    ctx.set_grid(raw3)
+    ctx.set_params(K3, flags3, None, 1.0 / 3.0)
+    ctx.discretize(rebuild_topology=True)
+    assert ctx.stats()["symbolic_reused"] == 0
+    cold3 = pa.Context(0, lib)
+    cold3.set_grid(raw3)
+    cold3.set_params(K3, flags3, None, 1.0 / 3.0)
+    cold3.discretize()
+    same(mats(ctx), mats(cold3), exact_values=True)
+    return True
+
+
+def check_mpsa_contrast_case(lib, name: str):
+    """Stiffness contrasts of 1e8 ... 1e12 between cells sharing a node: the interaction regions beyond
+    1e6 are assembled and eliminated in double-double (``pfv_stats.mpsa_contrast_regions`` says how many).  The device must
+    be within 1e-10 of the matrices the reference's own local systems have in 60-digit arithmetic -- and of the matrices
+    ``pp.Mpsa`` returned wherever those are themselves that close to the exact ones (beyond ~1e10 the reference's FP64
+    inverse is the side that is off, by 1e-7 on the tetrahedral 1e12 fixture).  With ``PFV_MPSA_DD=0`` (the FP64 body on
+    every region: the round-5 state) the same comparison must FAIL on at least one fixture: the test of the test."""
+    from tests._golden import MpsaContrastCase
+
+    c = MpsaContrastCase(name)
+
+    def run():
+        ctx = pa.Context(0, lib)
+        ctx.set_grid(c.grid)
+        ctx.mpsa_set_params(c.stiffness, c.grid["cell_volumes"], c.bc["is_dir"], c.bc["is_neu"], mo.default_eta(c.grid["name"]))
+        ctx.mpsa_discretize()
+        mats = {k: ctx.matrix(MPSA_WHICH[k]) for k in MPSA_KEYS}
+        st = ctx.stats()
+        ctx.close()
+        return mats, st
+
+    mats, st = run()
+    assert st["mpsa_contrast_regions"] > 0, st
+    assert st["mpsa_max_contrast"] >= 10.0 ** (c.decades - 1.5), st
+    worst = 0.0
+    for k in MPSA_KEYS:
+        e_exact = rel_max_err(mats[k], c.exact[k])
+        worst = max(worst, e_exact)
+        assert e_exact < 1e-10, (name, k, "vs exact", e_exact)
+        e_ref = rel_max_err(mats[k], c.ref[k])
+        assert e_ref < max(1e-10, 4.0 * c.ref_off_exact[k]), (name, k, "vs reference", e_ref, c.ref_off_exact[k])
+    return worst
+
+
+def mpsa_contrast_fp64_body_misses(lib):
+    """The same fixtures with the double-double body switched off: the FP64 condensed system loses eps x contrast."""
+    from tests._golden import MpsaContrastCase, mpsa_contrast_case_names
+
+    os.environ["PFV_MPSA_DD"] = "0"
+    try:
+        worst = 0.0
+        for name in mpsa_contrast_case_names():
+            c = MpsaContrastCase(name)
+            ctx = pa.Context(0, lib)
+            ctx.set_grid(c.grid)
+            ctx.mpsa_set_params(c.stiffness, c.grid["cell_volumes"], c.bc["is_dir"], c.bc["is_neu"], mo.default_eta(c.grid["name"]))
+            try:
+                ctx.mpsa_discretize()
+            except pa.PorefvError:
+                worst = max(worst, 1.0)  # ("singular" where the reference returns: the other face of the same loss)
+                continue
+            assert ctx.stats()["mpsa_contrast_regions"] > 0   # (counted although not treated: the fence)
+            for k in MPSA_KEYS:
+                worst = max(worst, rel_max_err(ctx.matrix(MPSA_WHICH[k]), c.exact[k]))
+            ctx.close()
+        return worst
+    finally:
+        del os.environ["PFV_MPSA_DD"]

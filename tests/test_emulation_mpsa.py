@@ -4,7 +4,7 @@ import pytest
 
 import porepy_amd as pa
 from tests import _parity as P
-from tests._golden import mpsa_case_names
+from tests._golden import mpsa_case_names, mpsa_contrast_case_names
 
 
 @pytest.fixture(scope="module")
@@ -197,3 +197,12 @@ def test_biot_coupling_terms_on_a_whole_grid_against_the_reference(lib):
     for k, v in out.items():
         if isinstance(v, list):
             assert max(v) < 1e-12, (k, v)
+
+
+@pytest.mark.parametrize("name", mpsa_contrast_case_names())
+def test_stiffness_contrasts_of_1e8_to_1e12_between_neighbouring_cells(lib, name):
+    assert P.check_mpsa_contrast_case(lib, name) < 1e-10
+
+
+def test_the_fp64_body_alone_misses_the_contrast_fixtures(lib):
+    assert P.mpsa_contrast_fp64_body_misses(lib) > 1e-9

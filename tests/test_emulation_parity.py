@@ -138,6 +138,10 @@ def test_rediscretize_with_new_parameters_reuses_topology(lib):
     assert d.context(g).stats()["num_sub_half_faces"] == st1["num_sub_half_faces"]
 
 
+def test_rebuilt_topology_keeps_the_patterns_it_proves_unchanged(lib):
+    assert P.symbolic_reuse_on_rebuilt_topology(lib)
+
+
 @pytest.mark.parametrize("name", ["partial_cart2d_5x5", "partial_tet3d_3x3x3"])
 def test_partial_discretization_and_update(lib, name):
     P.check_partial_case(lib, name)

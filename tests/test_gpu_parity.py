@@ -74,6 +74,12 @@ def test_deterministic_bitwise(lib):
         assert np.array_equal(a.data, b.data), k
 
 
+def test_rebuilt_topology_keeps_the_patterns_it_proves_unchanged(lib):
+    # (the device path runs the interaction-region kernel alone when the patterns are kept, beside the symbolic phase
+    # otherwise: both orders of events must leave the bits of a cold handle)
+    assert P.symbolic_reuse_on_rebuilt_topology(lib, n=10)
+
+
 def test_config_c2_scale_properties(lib):
     """BASELINE config 2 (196 608 tetrahedra): exact linear field, zero flux for constant
     pressure — size-independent properties; the oracle is too slow at this size."""
