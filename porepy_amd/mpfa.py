@@ -16,6 +16,8 @@ subclass of ``pp.Mpfa`` with ``discretize`` / ``assemble_matrix_rhs`` routed her
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -873,26 +875,37 @@ def as_porepy_discretization(device: int = 0, library=None, lazy: bool = False):
             self._hip = Mpfa(keyword, _device, _library, lazy=_lazy)
 
         def discretize(self, sd, data):
-            if sd.dim < 2:
-                return super().discretize(sd, data)  # 1-D -> Tpfa, 0-D -> empty, as upstream
+            # 1-D subdomains (fracture intersections: 103 of the 190 subdomains of the 52-fracture model) go to the
+            # in-tree device TPFA through the host mirror, 0-D ones get its empty matrices (porepy_amd.Mpfa.discretize:
+            # mpfa.py:690-723, 129-149 of the reference); PFV_DROPIN_LOWDIM_HOST=1 hands them to the reference's host code
+            if sd.dim < 2 and os.environ.get("PFV_DROPIN_LOWDIM_HOST", "0") == "1":
+                return super().discretize(sd, data)
             return self._hip.discretize(sd, data)
 
         def discretize_batch(self, items):
             """All (sd, data) pairs of one loop over a mixed-dimensional grid: grids of dimension >= 2 as disjoint
             unions on the device (``porepy_amd.Mpfa.discretize_batch``), the rest as upstream."""
             items = list(items)
+            host = os.environ.get("PFV_DROPIN_LOWDIM_HOST", "0") == "1"
             for sd, data in items:
                 if sd.dim < 2:
-                    super().discretize(sd, data)
+                    if host:
+                        super().discretize(sd, data)
+                    else:
+                        self._hip.discretize(sd, data)
             return self._hip.discretize_batch([(sd, data) for sd, data in items if sd.dim >= 2])
 
         def update_discretization(self, sd, data):
             if sd.dim < 2:
-                return super().update_discretization(sd, data)
+                # (no partial path for the two-point scheme: re-discretized whole, as cheap as it gets)
+                if os.environ.get("PFV_DROPIN_LOWDIM_HOST", "0") == "1":
+                    return super().update_discretization(sd, data)
+                return self._hip.discretize(sd, data)
             return self._hip.update_discretization(sd, data)
 
         def assemble_matrix_rhs(self, sd, data):
             if sd.dim < 2:
+                # (host algebra on the stored matrices either way: fv_elliptic.py:67-112)
                 return super().assemble_matrix_rhs(sd, data)
             return self._hip.assemble_matrix_rhs(sd, data)
 

@@ -163,9 +163,11 @@ def test_all_four_matrices_and_the_displacement_field_on_a_whole_grid_against_th
     out = P.mpsa_whole_grid_check(lib, n)
     print("MPSA whole grid vs reference:", {k: v for k, v in out.items() if k != "reference"})
     assert out["cells"] == cells
+    # (the assertion says what the data say -- observed <= 4.7e-15 for the matrices, 7.9e-15 for |u| at 511 104 cells: a
+    # block of ~500 rows x ~600 entries within 1e-13 bounds a single wrong entry to ~3e-8 of a mean entry)
     for k in P.MPSA_KEYS:
-        assert max(out[k]) < 1e-10, (k, out[k])
-    assert out["u_norm_rel_diff"] < 1e-10 and out["u_block_squares_worst_rel_diff"] < 1e-9, out
+        assert max(out[k]) < 1e-13, (k, out[k])
+    assert out["u_norm_rel_diff"] < 1e-12 and out["u_block_squares_worst_rel_diff"] < 1e-9, out
 
 
 def test_biot_coupling_terms_on_a_whole_grid_against_the_reference(lib):
@@ -178,7 +180,7 @@ def test_biot_coupling_terms_on_a_whole_grid_against_the_reference(lib):
     assert out["cells"] == 48000
     for k, v in out.items():
         if isinstance(v, list):
-            assert max(v) < 1e-10, (k, v)
+            assert max(v) < 1e-13, (k, v)  # (observed <= 2.1e-15)
 
 
 @pytest.mark.parametrize("name", mpsa_contrast_case_names())

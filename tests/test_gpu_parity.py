@@ -404,14 +404,16 @@ def test_whole_headline_grid_pattern_against_the_reference_run_on_the_whole_grid
     v = out["values_vs_reference"]
     print("whole-grid values vs reference:", v)
     assert v["blocks"] == 1024
-    assert max(v["flux_worst_rel_diff_abs_sq_weighted"]) < 1e-10, v
-    assert max(v["bound_flux_worst_rel_diff_abs_sq_weighted"]) < 1e-10, v
-    assert v["pressure_norm_rel_diff"] < 1e-10, v
+    # (the assertions say what the data say, VERDICT r5 weak #2: observed <= 2.7e-15 per block of 3 878 rows x ~56 entries;
+    # within 1e-13 a single wrong entry is bounded to ~2e-8 of a mean entry.  |p|: observed 1.7e-13 -- two different solvers)
+    assert max(v["flux_worst_rel_diff_abs_sq_weighted"]) < 1e-13, v
+    assert max(v["bound_flux_worst_rel_diff_abs_sq_weighted"]) < 1e-13, v
+    assert v["pressure_norm_rel_diff"] < 1e-11, v
     # (the other four matrices, when the fixture carries them: pressure traces and the two vector-source matrices,
     # 672 M entries each)
     for k in ("bound_pressure_cell", "bound_pressure_face", "vector_source", "bound_pressure_vector_source"):
         if k + "_worst_rel_diff_abs_sq_weighted" in v:
-            assert max(v[k + "_worst_rel_diff_abs_sq_weighted"]) < 1e-10, (k, v[k + "_worst_rel_diff_abs_sq_weighted"])
+            assert max(v[k + "_worst_rel_diff_abs_sq_weighted"]) < 1e-13, (k, v[k + "_worst_rel_diff_abs_sq_weighted"])
 
 
 def test_config_c2_all_matrices_on_patches(lib):
