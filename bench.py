@@ -1144,6 +1144,35 @@ def main():
         except Exception as e:  # secondary line only
             c4 = {"error": repr(e)}
 
+    # ---- every rank's view of the run (N > 1; VERDICT r5 item 8: the first run on several GPUs must yield a diagnosable
+    # curve, not one number): phases of the last timed step by the library's own HIP events, the step times by this rank's
+    # clock, sizes, what the process group looks like from here, what travelled.  One all_gather_object after the clock stopped.
+    per_rank = None
+    if dist is not None:
+        try:
+            mine = {
+                "rank": rank, "local_rank": local_rank,
+                "device": torch.cuda.get_device_name(local_rank) if torch.cuda.is_available() else "cpu",
+                "ranks_seen_by_rccl": int(dist.get_world_size()), "backend": str(dist.get_backend()),
+                "cells_owned": int(nc), "cells_with_halo": int(nloc), "halo_fraction": float(nloc - nc) / max(float(nloc), 1.0),
+                "phases_ms": {k: float(st[k]) for k in ("topology_ms", "symbolic_ms", "node_ms", "face_ms", "assemble_ms",
+                                                        "solve_ms", "discretize_ms", "amg_setup_ms") if k in st},
+                "kept": {"csr_patterns": int(st.get("symbolic_reused", 0)), "spmv_windows": int(st.get("win_reused", 0)),
+                         "amg_aggregate_maps": int(st.get("amg_maps_reused", 0))},
+                "amg": {"levels": int(st.get("amg_levels", 0)), "coarsest_rows": int(st.get("amg_coarsest_rows", 0)),
+                        "operator_complexity": float(st.get("amg_operator_complexity", 0.0))},
+                "launches": {"krylov_loop": int(st.get("solve_launches", 0)), "amg_setup": int(st.get("amg_setup_launches", 0))},
+                "step_ms_by_this_ranks_clock": [round(t, 2) for t, _ in each[:32]],
+                "iterations": [i for _, i in each[:32]],
+                "transport": (info.get("transport") if isinstance(info, dict) else None),
+                "halo_bytes_per_exchange": (info.get("halo_bytes_per_exchange") if isinstance(info, dict) else None),
+                "overlap_interior_boundary": os.environ.get("PFV_SHARD_OVERLAP", "0"),
+            }
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        except Exception as e:  # (diagnostics only: never costs the line)
+            per_rank = [{"error": repr(e)}]
+
     if rank == 0:
         res_true = None
         try:
@@ -1229,6 +1258,7 @@ def main():
             "solve_launches": {"krylov_loop": int(st.get("solve_launches", 0)), "amg_setup": int(st.get("amg_setup_launches", 0)),
                                "note": "this library's kernel dispatches of the last timed solve (rocPRIM primitives, memsets and copies not counted)"},
             "whole_grid_check": whole_grid,
+            "per_rank": per_rank,
             "assembly": assembly, "operator_api": opapi, "cpu_baseline": cpu, "cpu_baseline_headline_grid": cpu_headline,
             "config_c2": c2, "config_c4": c4,
             "config_c5": (config_c5(args.c5) if (world == 1 and args.n_side == 69 and (args.c5 or not args.no_extra_configs)) else None),

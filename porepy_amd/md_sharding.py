@@ -17,9 +17,15 @@ loop would have left: the AD assembly of the Jacobian (which the reference does 
 ``sharded_discretization(pp, ...)`` rebinds ``pp.ad.discretize_from_list`` for the duration of a ``with`` block, so
 an unmodified model shards its discretization -- the same kind of rebind as ``pp.Mpfa = HipMpfa``.
 
-A single large grid is not split here (that is ``distributed.extract_subdomain`` / ``ShardedCsr``: cells + one node
-ring): with one 3-D grid carrying most of the cells, the speed-up of this loop is bounded by
-``sum(cost) / max(cost)`` -- ``plan()`` reports it.
+With one 3-D grid carrying most of the cells the speed-up of a loop that hands out WHOLE grids is bounded by
+``sum(cost) / max(cost)`` (2.3 on the 52-fracture model).  Round 6 composes the two partitions: a job that would bound the
+loop -- cost above the mean load per rank -- and whose discretization object can discretize one PIECE of a grid
+(``discretize_piece`` / ``merge_piece_payloads``: ``porepy_amd.Mpfa`` and its drop-in subclass; cells along a Morton curve,
+one node ring of overlap, ``distributed.extract_subdomain`` -- the routine the cell-sharded single-grid path uses) is cut into
+piece jobs that are dealt out like any other job; the rows travel in the same single exchange and EVERY rank merges them
+(host scipy, as the reference's own merge of its sub-problems, numerics/fv/mpfa.py:298-372), so all ranks again hold what
+the serial loop would have left -- to rounding: the rows of a face two pieces computed are averaged.  ``Plan.bound`` is then
+``sum(cost) / max(cost)`` over the PIECE jobs.
 """
 from __future__ import annotations
 
@@ -39,6 +45,7 @@ class Job:
     is_interface: bool
     cost: float = 0.0
     owner: int = 0
+    piece: tuple | None = None   # (index, number of pieces, index of the parent job in the reference's loop order)
 
 
 @dataclass
@@ -46,6 +53,7 @@ class Plan:
     jobs: list
     world: int
     load: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    serial_cost: float = 0.0   # cost of the undivided loop (pieces recompute a node ring: their costs add up to more)
 
     @property
     def bound(self) -> float:
@@ -60,6 +68,10 @@ class Plan:
 
     def summary(self) -> dict:
         return {"jobs": len(self.jobs), "world": self.world, "load": [float(x) for x in self.load],
+                "speedup_vs_the_serial_loop_by_cost_model": (float(self.serial_cost / self.load.max())
+                                                             if self.load.size and self.load.max() > 0 and self.serial_cost > 0 else None),
+                "piece_jobs": int(sum(1 for j in self.jobs if j.piece is not None)),
+                "subdomains_cut_into_pieces": len({j.piece[2] for j in self.jobs if j.piece is not None}),
                 "speedup_by_cost_model": self.speedup, "bound_total_over_largest_job": self.bound,
                 "jobs_per_rank": [int(sum(1 for j in self.jobs if j.owner == r)) for r in range(self.world)]}
 
@@ -83,27 +95,48 @@ def default_cost(discr, grid, is_interface: bool) -> float:
     return 0.02 * n + 1.0
 
 
-def plan(discretizations: dict, world: int, cost=None, is_interface=None) -> Plan:
+PIECE_OVERLAP = 1.15  # cost of a piece relative to its share of the cells: the node ring it recomputes
+
+
+def plan(discretizations: dict, world: int, cost=None, is_interface=None, split: bool = True) -> Plan:
     """The jobs of ``discretize_from_list`` in the reference's own order, with an owner each.
 
     Longest-processing-time-first: jobs by decreasing cost (ties: loop order) onto the least loaded rank (ties:
-    lowest rank) -- deterministic, every rank computes the same plan without talking."""
+    lowest rank) -- deterministic, every rank computes the same plan without talking.
+    ``split``: a subdomain job whose cost exceeds the mean load per rank, on an object with ``discretize_piece``, becomes
+    ``k`` piece jobs (``k`` = the smallest number of pieces that brings one piece under half the mean load, at most
+    ``2 * world``); their ``piece`` field carries (index, k, position of the parent in the loop)."""
     cost = cost or default_cost
     if is_interface is None:
         def is_interface(g):
             return hasattr(g, "mortar_to_primary_int") or type(g).__name__ == "MortarGrid"
-    jobs = []
+    whole = []
     for discr in discretizations:
         for grid in discretizations[discr]:
             intf = bool(is_interface(grid))
-            jobs.append(Job(discr, grid, intf, float(cost(discr, grid, intf))))
+            whole.append(Job(discr, grid, intf, float(cost(discr, grid, intf))))
+    jobs = []
+    world_i = max(1, int(world))
+    mean = sum(j.cost for j in whole) / world_i
+    for pos, j in enumerate(whole):
+        can = (split and world_i > 1 and not j.is_interface and hasattr(j.discr, "discretize_piece")
+               and hasattr(j.discr, "merge_piece_payloads") and j.cost > mean and getattr(j.grid, "dim", 0) >= 2)
+        if not can:
+            jobs.append(j)
+            continue
+        # pieces of at most HALF the mean load: the greedy assignment below then ends within a few per cent of the mean
+        # (a job that is all of the work on 4 ranks: 8 pieces, two per rank; pieces of a whole mean load: 5, one rank
+        # takes two -- 2.5x instead of 3.5x)
+        k = int(min(2 * world_i, max(2, np.ceil(2.0 * PIECE_OVERLAP * j.cost / max(mean, 1e-300)))))
+        for p in range(k):
+            jobs.append(Job(j.discr, j.grid, False, PIECE_OVERLAP * j.cost / k, 0, (p, k, pos)))
     load = np.zeros(max(1, int(world)))
     order = sorted(range(len(jobs)), key=lambda i: (-jobs[i].cost, i))
     for i in order:
         r = int(np.argmin(load))
         jobs[i].owner = r
         load[r] += jobs[i].cost
-    return Plan(jobs, max(1, int(world)), load)
+    return Plan(jobs, max(1, int(world)), load, float(sum(j.cost for j in whole)))
 
 
 _ABSENT = object()
@@ -164,9 +197,22 @@ def _run(pp, mdg, job: Job, slots):
             pass
 
 
+def _merge_pieces(pp, mdg, pl: Plan, entries: dict, slots_of: dict) -> None:
+    """All pieces of ONE parent job are in ``entries`` (job index -> [("__piece__", p, k, payload)]): merged into the
+    grid's data dictionary by the discretization object -- on every rank, from the same payloads in the same order."""
+    idx = sorted(entries)
+    job = pl.jobs[idx[0]]
+    k = job.piece[1]
+    payloads = [entries[i][0][3] for i in idx]
+    if len(payloads) != k:
+        raise RuntimeError(f"piece exchange incomplete: {len(payloads)} of {k} pieces of one subdomain arrived")
+    data = slots_of[idx[0]][0] if idx[0] in slots_of else _matrix_slots(pp, mdg, job)[0]
+    job.discr.merge_piece_payloads(job.grid, data, payloads)
+
+
 def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None, rank: int | None = None,
                                  world: int | None = None, cost=None, exchange=None, stats: dict | None = None,
-                                 batch: bool = True):
+                                 batch: bool = True, split: bool = True):
     """``pp.ad.discretize_from_list`` (ad_utils.py:281-308) with the (discretization, grid) pairs dealt out to ranks.
 
     ``exchange(payload) -> list of payloads by rank`` defaults to ``torch.distributed.all_gather_object`` on
@@ -185,7 +231,7 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
             rank = dist.get_rank(group) if rank is None else rank
         else:
             world, rank = 1, 0
-    pl = plan(discretizations, world, cost, is_interface=lambda g: isinstance(g, pp.MortarGrid))
+    pl = plan(discretizations, world, cost, is_interface=lambda g: isinstance(g, pp.MortarGrid), split=split)
     mine: dict = {}
     mine_objects: dict = {}  # the same entries with the objects as stored here (device-resident proxies stay what they are)
     own = [i for i, job in enumerate(pl.jobs) if job.owner == rank]
@@ -197,14 +243,22 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
         by_discr: dict = {}
         for i in own:
             job = pl.jobs[i]
-            if not job.is_interface and hasattr(job.discr, "discretize_batch"):
+            if not job.is_interface and job.piece is None and hasattr(job.discr, "discretize_batch"):
                 by_discr.setdefault(id(job.discr), (job.discr, []))[1].append(i)
         for discr, idx in by_discr.values():
             if len(idx) > 1:
                 discr.discretize_batch([(pl.jobs[i].grid, slots_of[i][0]) for i in idx])
                 done.update(idx)
                 batches += 1
+    piece_payloads: dict = {}  # job index -> payload of a piece this rank discretized
     for i in own:
+        if pl.jobs[i].piece is not None:
+            # one piece of a large subdomain: nothing is stored here, the rows travel and every rank merges them below
+            p, k, _ = pl.jobs[i].piece
+            piece_payloads[i] = pl.jobs[i].discr.discretize_piece(pl.jobs[i].grid, slots_of[i][0], p, k)
+            mine[i] = [("__piece__", p, k, piece_payloads[i])]
+            mine_objects[i] = mine[i]
+            continue
         if i not in done:
             _run(pp, mdg, pl.jobs[i], slots_of[i])
         out, kept = [], []
@@ -218,6 +272,8 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
         mine[i] = out
         mine_objects[i] = kept
     sent = 0
+    if world == 1 and piece_payloads:  # (cannot happen with plan(): one rank never splits; kept for callers' own plans)
+        _merge_pieces(pp, mdg, pl, {i: mine[i] for i in piece_payloads}, slots_of)
     if world > 1:
         if exchange is None:
             import torch.distributed as dist
@@ -234,12 +290,25 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
         for r, theirs in enumerate(exchange(mine)):
             for i, payload in (mine_objects if r == rank else theirs).items():
                 results[i] = payload
+        merged_parents = set()
         for i in sorted(results):
             slots = slots_of[i] if i in slots_of else _matrix_slots(pp, mdg, pl.jobs[i])
+            if pl.jobs[i].piece is not None:
+                # the pieces of one parent job are merged where its FIRST piece stands in the order of application
+                parent = pl.jobs[i].piece[2]
+                if parent not in merged_parents:
+                    merged_parents.add(parent)
+                    _merge_pieces(pp, mdg, pl, {q: results[q] for q in results
+                                                if pl.jobs[q].piece is not None and pl.jobs[q].piece[2] == parent}, slots_of)
+                continue
             for (s, kw, name, v) in results[i]:
                 slots[s].setdefault(pp.DISCRETIZATION_MATRICES, {}).setdefault(kw, {})[name] = v
         for out in mine.values():
             for (_, _, _, v) in out:
+                if isinstance(v, dict):  # a piece's rows
+                    for trip in list(v.get("mats", {}).values()) + ([v["system"]] if v.get("system") is not None else []):
+                        sent += sum(int(np.asarray(x).nbytes) for x in trip)
+                    continue
                 if sps.issparse(v):
                     m = v.tocsr() if not sps.isspmatrix_csr(v) and not sps.isspmatrix_csc(v) else v
                     sent += m.data.nbytes + m.indices.nbytes + m.indptr.nbytes
@@ -260,14 +329,14 @@ def discretize_from_list_sharded(discretizations: dict, mdg, pp=None, group=None
 
 @contextlib.contextmanager
 def sharded_discretization(pp, group=None, rank: int | None = None, world: int | None = None, cost=None,
-                           exchange=None, stats: dict | None = None, batch: bool = True):
+                           exchange=None, stats: dict | None = None, batch: bool = True, split: bool = True):
     """Rebind ``pp.ad.discretize_from_list`` (the loop every model discretizes through: equation_system.py:1559,
     solution_strategy.py:995 / 1014, operators.py:487) to the sharded loop inside the ``with`` block."""
     orig = pp.ad.discretize_from_list
 
     def sharded(discretizations, mdg):
         return discretize_from_list_sharded(discretizations, mdg, pp=pp, group=group, rank=rank, world=world,
-                                            cost=cost, exchange=exchange, stats=stats, batch=batch)
+                                            cost=cost, exchange=exchange, stats=stats, batch=batch, split=split)
 
     pp.ad.discretize_from_list = sharded
     try:

@@ -333,72 +333,95 @@ class Mpfa:
         complete), discretized on the device on its own, and the rows of the faces of its own cells are merged
         into the global matrices on the host; a face between two pieces is computed by both and averaged, as
         the reference does.  One piece is resident in HBM at a time.  The system matrix div @ flux is taken
-        from the pieces too (rows of a piece's own cells are complete there)."""
-        import scipy.sparse as sps
+        from the pieces too (rows of a piece's own cells are complete there).
 
+        The same two halves serve the cell-sharded discretization of ONE large subdomain across ranks
+        (``discretize_piece`` on the rank that owns a piece, ``merge_pieces`` on every rank after the exchange:
+        porepy_amd/md_sharding.py)."""
+        owner = partition_cells(sd, nparts)
+        payloads = [self._piece_payload(sd, data, owner, r, eta) for r in range(nparts) if np.any(owner == r)]
+        self.merge_pieces(sd, data, payloads)
+
+    def _piece_payload(self, sd, data: dict, owner, r: int, eta: float) -> dict:
+        """Rows of the faces (and of ``div @ flux``: of the cells) piece ``r`` of the cell partition ``owner`` owns, as
+        COO triplets in GLOBAL numbering -- plain numpy arrays: what a rank sends to the others."""
         from .distributed import extract_subdomain
 
         pd = data[PARAMETERS][self.keyword]
-        md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
         raw = grid_to_raw(sd)
-        nd, nc, nf = sd.dim, sd.num_cells, sd.num_faces
+        nd = sd.dim
         kval = np.asarray(pd["second_order_tensor"].values, dtype=float)
         bnd = pd["bc"]
         flags = bc_flags(bnd)
         robin = np.asarray(bnd.robin_weight, dtype=float)
-        owner = partition_cells(sd, nparts)
+        out = {"piece": int(r), "mats": {}, "faces": np.zeros(0, np.int64), "system": None}
+        if not np.any(owner == r):
+            return out
+        lp = extract_subdomain(raw, owner, r)
+        ctx = _lib.Context(self.device, self._library)
+        try:
+            ctx.set_grid(lp.raw)
+            lfl = flags[lp.face_gid].copy()
+            lfl[lp.artificial_boundary] = _lib.BC_NEU  # never touches a node of an own cell
+            ctx.set_params(np.ascontiguousarray(kval[:, :, lp.cell_gid]), lfl,
+                           np.ascontiguousarray(robin[lp.face_gid]), eta, None)
+            try:
+                ctx.discretize(rebuild_topology=True)
+            except _lib.PorefvError as e:
+                if e.status == 1:
+                    raise ValueError("Error in inversion of local linear systems") from e
+                if e.status == 2:
+                    raise AssertionError(e.message) from e
+                raise
+            cfp = lp.raw["cf_indptr"]
+            own_faces = np.unique(lp.raw["cf_indices"][: cfp[lp.n_own]])  # faces of the piece's own cells
+            out["faces"] = np.asarray(lp.face_gid[own_faces], dtype=np.int64)
+            vcol = (nd * lp.cell_gid[:, None] + np.arange(nd)[None, :]).ravel()
+            for name, which in _KEYS:
+                M = ctx.matrix_rows(which, own_faces).tocoo()
+                cmap = (vcol if "vector_source" in name else
+                        lp.face_gid if name in ("bound_flux", "bound_pressure_face") else lp.cell_gid)
+                out["mats"][name] = (np.asarray(lp.face_gid[own_faces][M.row], dtype=np.int64),
+                                     np.asarray(cmap[M.col], dtype=np.int64), np.asarray(M.data, dtype=float))
+            ctx.assemble(np.zeros(lp.face_gid.size), None, None)
+            S = ctx.matrix_rows(_lib.MAT_SYSTEM, np.arange(lp.n_own)).tocoo()
+            out["system"] = (np.asarray(lp.cell_gid[S.row], dtype=np.int64), np.asarray(lp.cell_gid[S.col], dtype=np.int64),
+                             np.asarray(S.data, dtype=float))
+        finally:
+            ctx.close()
+        return out
+
+    def merge_pieces(self, sd, data: dict, payloads) -> None:
+        """The global matrices from the pieces' rows (host scipy, as the reference's own merge mpfa.py:298-372): rows of
+        a face two pieces computed are averaged; pieces in ascending order, so every rank that merges the same payloads
+        stores the same bits."""
+        import scipy.sparse as sps
+
+        pd = data[PARAMETERS][self.keyword]
+        md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
+        nd, nc, nf = sd.dim, sd.num_cells, sd.num_faces
         ncols = {"flux": nc, "bound_flux": nf, "bound_pressure_cell": nc, "bound_pressure_face": nf,
                  "vector_source": nd * nc, "bound_pressure_vector_source": nd * nc}
-        acc = {name: ([], [], []) for name, _ in _KEYS}
-        sysacc = ([], [], [])
+        payloads = sorted((p for p in payloads if p.get("system") is not None), key=lambda p: p["piece"])
         count = np.zeros(nf, dtype=np.int64)
-        for r in range(nparts):
-            if not np.any(owner == r):
-                continue
-            lp = extract_subdomain(raw, owner, r)
-            ctx = _lib.Context(self.device, self._library)
-            try:
-                ctx.set_grid(lp.raw)
-                lfl = flags[lp.face_gid].copy()
-                lfl[lp.artificial_boundary] = _lib.BC_NEU  # never touches a node of an own cell
-                ctx.set_params(np.ascontiguousarray(kval[:, :, lp.cell_gid]), lfl,
-                               np.ascontiguousarray(robin[lp.face_gid]), eta, None)
-                try:
-                    ctx.discretize(rebuild_topology=True)
-                except _lib.PorefvError as e:
-                    if e.status == 1:
-                        raise ValueError("Error in inversion of local linear systems") from e
-                    if e.status == 2:
-                        raise AssertionError(e.message) from e
-                    raise
-                cfp = lp.raw["cf_indptr"]
-                own_faces = np.unique(lp.raw["cf_indices"][: cfp[lp.n_own]])  # faces of the piece's own cells
-                count[lp.face_gid[own_faces]] += 1
-                vcol = (nd * lp.cell_gid[:, None] + np.arange(nd)[None, :]).ravel()
-                for name, which in _KEYS:
-                    M = ctx.matrix_rows(which, own_faces).tocoo()
-                    cmap = (vcol if "vector_source" in name else
-                            lp.face_gid if name in ("bound_flux", "bound_pressure_face") else lp.cell_gid)
-                    rr, cc, vv = acc[name]
-                    rr.append(lp.face_gid[own_faces][M.row])
-                    cc.append(cmap[M.col])
-                    vv.append(M.data)
-                ctx.assemble(np.zeros(lp.face_gid.size), None, None)
-                S = ctx.matrix_rows(_lib.MAT_SYSTEM, np.arange(lp.n_own)).tocoo()
-                sysacc[0].append(lp.cell_gid[S.row])
-                sysacc[1].append(lp.cell_gid[S.col])
-                sysacc[2].append(S.data)
-            finally:
-                ctx.close()
+        for p in payloads:
+            count[p["faces"]] += 1
         scale = 1.0 / np.maximum(count, 1)
         for name, _ in _KEYS:
-            rr, cc, vv = (np.concatenate(x) if x else np.zeros(0) for x in acc[name])
-            M = sps.coo_matrix((vv * scale[rr.astype(np.int64)], (rr, cc)), shape=(nf, ncols[name])).tocsr()
+            if payloads:
+                rr = np.concatenate([p["mats"][name][0] for p in payloads])
+                cc = np.concatenate([p["mats"][name][1] for p in payloads])
+                vv = np.concatenate([p["mats"][name][2] for p in payloads])
+            else:
+                rr = cc = np.zeros(0, np.int64)
+                vv = np.zeros(0)
+            M = sps.coo_matrix((vv * scale[rr], (rr, cc)), shape=(nf, ncols[name])).tocsr()
             M.sum_duplicates()
             M.sort_indices()
             md[name] = M
-        A = sps.coo_matrix((np.concatenate(sysacc[2]), (np.concatenate(sysacc[0]), np.concatenate(sysacc[1]))),
-                           shape=(nc, nc)).tocsr()
+        A = sps.coo_matrix((np.concatenate([p["system"][2] for p in payloads]),
+                            (np.concatenate([p["system"][0] for p in payloads]),
+                             np.concatenate([p["system"][1] for p in payloads]))), shape=(nc, nc)).tocsr()
         A.sum_duplicates()
         A.sort_indices()
         self._split[id(sd)] = (sd, A)
@@ -406,6 +429,54 @@ class Mpfa:
         self._fingerprints.pop(id(sd), None)
         pd["active_cells"] = np.arange(nc)
         pd["active_faces"] = np.arange(nf)
+
+    def pieces_supported(self, sd, data: dict) -> bool:
+        """Whether this (grid, parameters) pair can be discretized piece by piece: a full discretization of a grid of
+        dimension >= 2 in its own coordinates, conditions per face, one continuity point for all sub-faces, no periodic
+        faces -- the cases ``discretize`` itself splits under ``partition_arguments`` (the same predicate)."""
+        pd = data[PARAMETERS][self.keyword]
+        if sd.dim < 2:
+            return False
+        partial = any(pd.get(k) is not None for k in ("specified_cells", "specified_faces", "specified_nodes"))
+        update = bool(pd.get("update_discretization", False))
+        vdim = pd.get("ambient_dimension", sd.dim)
+        subface = np.asarray(pd["bc"].is_dir).size != sd.num_faces
+        eta = pd.get("mpfa_eta", None)
+        eta_sub = eta is not None and np.asarray(eta).size != 1
+        return not (partial or update or subface or eta_sub or hasattr(sd, "periodic_face_map") or vdim != sd.dim
+                    or (sd.dim == 2 and plane_basis(grid_to_raw(sd)["nodes"]) is not None))
+
+    def discretize_piece(self, sd, data: dict, piece: int, nparts: int) -> dict:
+        """Piece ``piece`` of ``nparts`` of the cell partition of ``sd`` (``partition_cells``: along the Morton curve of the
+        cell centres, the same on every rank), discretized on this object's device; returns the payload ``merge_pieces``
+        takes.  Where the pair cannot be split (``pieces_supported``), piece 0 carries the whole discretization."""
+        if not self.pieces_supported(sd, data):
+            if piece != 0:
+                return {"piece": int(piece), "mats": {}, "faces": np.zeros(0, np.int64), "system": None, "whole": None}
+            self.discretize(sd, data)
+            md = data[DISCRETIZATION_MATRICES][self.keyword]
+            return {"piece": 0, "mats": {}, "faces": np.zeros(0, np.int64), "system": None,
+                    "whole": {name: md[name].tocsr() if hasattr(md[name], "tocsr") else md[name] for name, _ in _KEYS}}
+        pd = data[PARAMETERS][self.keyword]
+        eta = pd.get("mpfa_eta", None)
+        if eta is None:
+            eta = determine_eta(sd)
+        note_ignored_parameters(pd, self.keyword)
+        owner = partition_cells(sd, int(nparts))
+        return self._piece_payload(sd, data, owner, int(piece), float(eta))
+
+    def merge_piece_payloads(self, sd, data: dict, payloads) -> None:
+        """``merge_pieces`` for payloads that may carry an undivided discretization (``discretize_piece`` on a pair that
+        cannot be split)."""
+        whole = [p for p in payloads if p.get("whole")]
+        if whole:
+            md = data.setdefault(DISCRETIZATION_MATRICES, {}).setdefault(self.keyword, {})
+            md.update(whole[0]["whole"])
+            pd = data[PARAMETERS][self.keyword]
+            pd["active_cells"] = np.arange(sd.num_cells)
+            pd["active_faces"] = np.arange(sd.num_faces)
+            return
+        self.merge_pieces(sd, data, payloads)
 
     def _split_system(self, sd, data: dict, source=None):
         """(A, b) of a grid discretized in pieces: A from the pieces' device-side div @ flux, b from the merged
@@ -894,6 +965,12 @@ def as_porepy_discretization(device: int = 0, library=None, lazy: bool = False):
                     else:
                         self._hip.discretize(sd, data)
             return self._hip.discretize_batch([(sd, data) for sd, data in items if sd.dim >= 2])
+
+        def discretize_piece(self, sd, data, piece, nparts):
+            return self._hip.discretize_piece(sd, data, piece, nparts)
+
+        def merge_piece_payloads(self, sd, data, payloads):
+            return self._hip.merge_piece_payloads(sd, data, payloads)
 
         def update_discretization(self, sd, data):
             if sd.dim < 2:

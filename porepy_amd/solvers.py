@@ -322,6 +322,34 @@ class HipLinearSolver:
             elim = getattr(self, "_hip_interface_mask", None)
             if elim is None or not elim.any() or row_perm is None:
                 elim = None
+            shard = opts.get("sharded")
+            if shard is not None:
+                # The coupled Jacobian solved over the ranks of a process group (round 6: the md model with its
+                # discretization loop AND its Newton solves sharded): ``opts["sharded"] = {"dist": torch.distributed (or
+                # a stand-in with the same calls), "device": ..., "local_device_index": ...}``.  Unknowns are dealt out by
+                # position inside every variable-wide block -- the reference numbers a variable grid by grid, the 3-D
+                # matrix first: equal shares are a slab of matrix cells plus runs of whole fracture planes, lines and
+                # mortar grids (their unknowns reach the other ranks through the halo plan of ShardedCsr).
+                dist = shard["dist"]
+                world = int(dist.get_world_size())
+                owner = np.zeros(A.shape[0], dtype=np.int64)
+                for k in np.unique(block_of):
+                    idx = np.flatnonzero(block_of == k)
+                    owner[idx] = (np.arange(idx.size) * world) // idx.size
+                x, info = solve_block_system_sharded(A, b, block_of, owner, dist, rtol=float(opts.get("rtol", 1e-12)),
+                                                     maxit=int(opts.get("maxit", 4000)),
+                                                     device=str(shard.get("device", "cuda")),
+                                                     local_device_index=int(shard.get("local_device_index", 0)),
+                                                     library=self.hip_library,
+                                                     gauss_seidel=bool(opts.get("gauss_seidel", True)), row_perm=row_perm,
+                                                     eliminate=elim)
+                if not info["converged"]:
+                    raise RuntimeError(f"hip sharded block solver did not converge: {info}")
+                self.hip_solver_info = dict(info, sharded_world=world)
+                x = np.atleast_1d(x)
+                if self._apply_schur_complement_reduction():
+                    x = self.equation_system.expand_schur_complement_solution(x)
+                return x
             x, info = solve_block_system(A, b, block_of, method=_METHODS[solver],
                                          rtol=float(opts.get("rtol", 1e-12)), maxit=int(opts.get("maxit", 2000)),
                                          restart=int(opts.get("restart", 60)), context=self._hip_solver_context,

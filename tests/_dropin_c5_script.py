@@ -238,12 +238,29 @@ def main_sharded():
     n_serial = sum(calls.values())
     calls.clear()
     stats = {}
-    with md_sharding.sharded_discretization(pp, stats=stats):
-        sharded = run()
+    # C5_SPLIT=1 (round 6): the jobs that bound the loop -- the 3-D matrix grid under Darcy and Fourier -- are cut into
+    # cell pieces (node ring of overlap) that are dealt out with the fracture jobs; rows merged on every rank.  The
+    # default (0) hands out whole subdomains only, which reproduces the serial loop bit for bit.
+    split = os.environ.get("C5_SPLIT", "0") == "1"
+    with md_sharding.sharded_discretization(pp, stats=stats, split=split):
+        if split:
+            # ... and every Newton system solved SHARDED over the same ranks (solve_block_system_sharded through the
+            # HipLinearSolver mixin: interface fluxes condensed, unknowns dealt out by position inside every variable)
+            sharded = run(HipSolveModel, "hip_bicgstab", {"precond": "block", "rtol": 1e-13,
+                                                          "sharded": {"dist": dist, "device": "cpu"}})
+        else:
+            sharded = run()
     n_here = sum(v for k, v in calls.items() if ":" in k) + calls.get("grids_in_batch_calls", 0)
     same = bool(np.array_equal(serial["x"], sharded["x"]) and (serial["A"] != sharded["A"]).nnz == 0)
+    x_rel = float(np.linalg.norm(serial["x"] - sharded["x"]) / np.linalg.norm(serial["x"]))
+    a_rel = float(abs(serial["A"] - sharded["A"]).max() / abs(serial["A"]).max())
+    # what the same plan would be on 8 ranks (cost model only: nobody runs it here)
     gathered = [None] * world
-    dist.all_gather_object(gathered, {"rank": rank, "same": same, "device_calls_here": n_here,
+    dist.all_gather_object(gathered, {"rank": rank, "same": same, "x_rel_err": x_rel, "A_rel_err": a_rel,
+                                      "device_calls_here": n_here,
+                                      "sharded_solves": [dict(iterations=int(q.get("iterations", -1)),
+                                                              world=int(q.get("sharded_world", 0)))
+                                                         for q in sharded.get("solves", [])],
                                       "device_calls_serial": n_serial, "stats": stats,
                                       "device_unions": calls.get("device_unions", 0)})
     if rank == 0:

@@ -189,6 +189,42 @@ def test_c5_discretization_sharded_by_subdomain_under_gloo():
     assert sum(x["device_unions"] for x in ranks) >= 2
 
 
+def test_c5_matrix_grid_cut_into_cell_pieces_inside_the_sharded_loop_under_gloo():
+    """the pieces composed.  At four ranks the two jobs of the 3-D matrix grid (Darcy, Fourier) would
+    bound the loop at ~2.3x; ``md_sharding.plan`` cuts each into cell pieces (Morton partition + one node ring,
+    ``distributed.extract_subdomain``) that are dealt out together with the fracture jobs, every rank discretizes its
+    pieces through the rebound ``pp.Mpfa`` (``discretize_piece``), the rows travel in the loop's single exchange and are
+    merged on every rank.  The model's solution and last Jacobian equal those of the serial loop to 1e-10 on every rank
+    (rows of faces between two pieces are averaged: not bitwise), no rank repeats the whole 3-D grid, and the bound of
+    the plan by the cost model exceeds 6 at eight ranks."""
+    env = oracle.ref_env(extra_last=[ROOT])
+    if env is None:
+        pytest.skip("reference PorePy not present")
+    env.update({"PFV_DROPIN_LIBRARY": "emulation", "C5_FRACTURES": "16", "C5_N_SIDE": "10", "C5_MAX_EXTENT": "6",
+                "OMP_NUM_THREADS": "2", "C5_SPLIT": "1"})
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tests", "_dropin_c5_script.py"), "--sharded"],
+                       env=env, cwd="/tmp", capture_output=True, text=True, timeout=2400)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, r.stderr[-3000:]
+    out = json.loads(line[-1][7:])
+    assert out["world"] == 4 and out["fractures"] == 16
+    ranks = out["ranks"]
+    assert all(x["x_rel_err"] < 1e-10 and x["A_rel_err"] < 1e-10 for x in ranks), [(x["x_rel_err"], x["A_rel_err"]) for x in ranks]
+    first = ranks[0]["stats"]["plans"][0]
+    assert first["subdomains_cut_into_pieces"] == 2 and first["piece_jobs"] >= 4, first
+    assert first["bound_total_over_largest_job"] > 4.0 and first["speedup_by_cost_model"] > 3.0, first
+    assert all(x["stats"]["matrix_bytes_sent"] > 0 for x in ranks)
+    # ... and the Newton systems of that run were solved sharded over the same four ranks
+    assert all(len(x["sharded_solves"]) >= 3 and all(q["world"] == 4 for q in x["sharded_solves"]) for x in ranks)
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_merged_operator_parse_and_flux_products_on_the_device(variant):
     """``MergedOperator.parse`` (numerics/ad/ad_utils.py:597-663) and the matrix products of the flux
