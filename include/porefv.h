@@ -139,6 +139,9 @@ typedef struct {
                                      differ by more than PFV_MPSA_CONTRAST_LIMIT (1e6) -- the regions that were assembled and
                                      eliminated in double-double arithmetic (mpsa_dd.inc) */
   double mpsa_max_contrast;       /* MPSA: the largest such ratio over all interaction regions (1: homogeneous) */
+  int64_t pipeline_runs;          /* > 0: the last pfv_mpfa_discretize ran the interaction-region kernel in this many runs on the
+                                     second stream with the face kernel following run by run on the first (node_ms is then the
+                                     span of the whole pipeline, face_ms what came after it); 0: one after the other */
 } pfv_stats;
 
 pfv_status pfv_create(int device, pfv_ctx** out);

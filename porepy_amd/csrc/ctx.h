@@ -16,6 +16,12 @@ constexpr int kMaxBlock = 255;     // local sub-face / sub-cell indices are stor
 // block-size classes of the interaction-region kernel (one launch, one LDS size per class)
 static const int kClassBounds[] = {4, 8, 12, 16, 24, 32, 40, 48, 64, 96, 128, 192, 255};
 constexpr int kNumClasses = 13;
+// PFV_PIPE_CHUNKS: runs of the node || face pipeline (0 / 1: off).  OFF -- measured on the MI355X at 2 M cells
+// (profiles/r06_ab_runs.txt): the pipeline's span 14.9 ms (K = 4 / 8 / 16 / 30: 14.8 / 14.9 / 15.2 / 16.0) against
+// 6.6 + 7.1 = 13.7 ms back to back: the two kernels share the device work-conservingly (the interaction-region kernel
+// holds 154 of the 160 KB of LDS of a CU, the face kernel's wavefronts wait for whole workgroups of it to retire), and the
+// ready-run-major face order the pipeline needs costs the face kernel 1.4 ms of table locality (8.5 against 7.1 ms).
+constexpr int kPipeChunksDefault = 0;
 
 // Per sub-face (face, node) record consumed by the face kernel: one 64-byte line, written whole by the
 // interaction-region kernel (by the lane of the sub-cell the flux is evaluated from).  It replaces the
@@ -153,6 +159,11 @@ struct pfv_ctx_impl {
   double bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {1, 1, 1};
   Buf<int32_t> node_order;    // [nn] nodes sorted by block-size class
   std::vector<int64_t> class_begin;  // host: first position of each size class in node_order
+  // node || face pipeline (topology.inc): runs of the largest size class, the faces that are ready after each of them
+  int pipe_chunks = 0, pipe_class = -1;     // 0: no pipeline on this grid
+  std::vector<int64_t> pipe_node_begin;     // [K + 1] positions in node_order: run q = [begin[q], begin[q + 1]) , q = 0 .. K - 1
+  std::vector<int32_t> pipe_face_begin;     // [K + 2] positions in face_order: faces ready after run q (0: the other classes) = [begin[q], begin[q + 1])
+  Buf<uint8_t> pipe_node_chunk;             // [nn] 0: not in the pipelined class, q + 1: run q of it
   int max_block = 0, max_deg = 0, max_face_nodes = 0, max_cell_faces = 0, max_bnd_per_node = 0;
   int64_t sum_block_sq = 0;   // sum of n(v)^2 (statistics)
   int64_t tab_len = 0, tabb_len = 0;
@@ -166,6 +177,7 @@ struct pfv_ctx_impl {
   Buf<double> tabb;           // [tabb_len] boundary nodes: T[:, lb] beta_lb (n x nb), then A^-1[:, lb] beta_lb
   Buf<SfRec> sf_rec;          // [nsf] see SfRec
   Buf<int32_t> face_ctr;      // work counters of the face kernel, one per XCD at 64-byte spacing (PFV_FACE_DYN)
+  unsigned face_ctr_next = 0;          // counter set of the next face-kernel launch (32 sets, cycled)
   Buf<FaceRec> face_rec;      // [nf] see FaceRec (written at the end of the symbolic phase)
   Buf<int32_t> status;        // [4] device status words: singular node, ...
 

@@ -389,6 +389,8 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
     pfv::Timer tm, tall;
     tall.start(s);
     bool node_done = false;
+    bool face_done = false;       // the face kernel ran inside the node || face pipeline
+    const bool with_vs = !(flags & PFV_DISCR_SKIP_VECTOR_SOURCE);
     bool cells_deferred = false;  // part 2 of the symbolic phase (pattern of A) still to be built
     if (!h->have_topology || !h->have_symbolic || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) {
       tm.start(s);
@@ -436,12 +438,51 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
       h->have_sub_symbolic = h->have_mpsa_sub_symbolic = false;
       }  // !keep_symbolic
     }
+#ifndef PFV_EMULATE
+    h->stats.pipeline_runs = 0;
+    if (!node_done && !h->subface_bc && h->aux_stream && h->pipe_chunks > 1 && h->have_symbolic &&
+        pfv::env_int("PFV_PIPE", 1) != 0) {
+      // ---- node || face pipeline (patterns in place: kept after a proved-equal topology, or a values-only call).  The
+      // interaction-region kernel is bound by instruction issue, the face kernel by memory traffic; back to back each
+      // leaves the other's resource idle.  The node kernel goes to the second stream in K runs of its largest size class
+      // (topology.inc); after run q an event releases, on the main stream, the face kernel over the faces whose nodes are
+      // all through -- one contiguous range of the ready-run-major face order.  The host enqueues node run, event, face
+      // range alternately; the device overlaps face range q with node run q + 1.  Same kernels on the same data: the
+      // matrices are bit for bit those of the sequential order (tests: PFV_PIPE=0 against 1).
+      // Interaction regions the unpivoted elimination hands to the redo list are only known once every run is through:
+      // they are redone then, and the faces around them recomputed (a handful per million nodes).
+      tm.start(s);
+      const int K = h->pipe_chunks;
+      std::vector<hipEvent_t> ev((size_t)K + 1, nullptr);
+      for (auto& e : ev) PFV_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      pfv::stream_t ns = h->aux_stream;
+      try {
+        pfv::StreamFork fork(s, ns);
+        const std::function<void(int)> after = [&](int q) {
+          PFV_HIP_CHECK(hipEventRecord(ev[q], ns));
+          PFV_HIP_CHECK(hipStreamWaitEvent(s, ev[q], 0));
+          const int64_t f0 = h->pipe_face_begin[q], f1 = h->pipe_face_begin[q + 1];
+          pfv::run_face_kernel(*h, with_vs, nullptr, 0, f0, f1 - f0);
+        };
+        pfv::launch_node_kernel(*h, nullptr, ns, &after);
+        fork.join();
+      } catch (...) {
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        throw;
+      }
+      for (auto& e : ev) (void)hipEventDestroy(e);
+      pfv::check_node_status(*h, s);  // (reads the flags: everything above is through; runs the redo list, if any)
+      if (h->stats.node_redo > 0) pfv::redo_faces_around_nodes(*h, with_vs, h->stats.node_redo);
+      h->stats.node_ms = tm.stop(s);
+      h->stats.pipeline_runs = K;
+      node_done = face_done = true;
+    }
+#endif
     if (!node_done) {
       tm.start(s);
       pfv::run_node_kernel(*h);
       h->stats.node_ms = tm.stop(s);
     }
-    const bool with_vs = !(flags & PFV_DISCR_SKIP_VECTOR_SOURCE);
     tm.start(s);
     if (h->subface_bc) {
       if (!h->have_sub_symbolic || (flags & PFV_DISCR_REBUILD_TOPOLOGY)) pfv::build_subface_symbolic(*h);
@@ -467,7 +508,7 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
                            nnzA_guess >= pfv::env_int("PFV_SPMV_WINDOW_MIN_NNZ", 20000);
       if (prebuild || prebuild_rows || cells_deferred) {
         pfv::StreamFork fork(s, h->aux_stream);
-        pfv::run_face_kernel(*h, with_vs);
+        if (!face_done) pfv::run_face_kernel(*h, with_vs);  // (face_done: it ran inside the node || face pipeline)
         h->stream = h->aux_stream;
         try {
           if (cells_deferred) {
@@ -517,7 +558,7 @@ pfv_status pfv_mpfa_discretize(pfv_ctx* h, uint32_t flags) {
         }
       } else
 #endif
-      pfv::run_face_kernel(*h, with_vs);
+      if (!face_done) pfv::run_face_kernel(*h, with_vs);
     }
     if (cells_deferred) pfv::build_symbolic(*h, 2);  // (no second stream was used)
     h->stats.face_ms = tm.stop(s);

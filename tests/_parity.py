@@ -2414,3 +2414,62 @@ def mpsa_contrast_fp64_body_misses(lib):
         return worst
     finally:
         del os.environ["PFV_MPSA_DD"]
+
+
+def node_face_pipeline_leaves_the_same_bits(lib, n=16, device=True):
+    """The node || face pipeline (interaction-region kernel in K runs on the second stream, the face kernel following run
+    by run on the first; ready-run-major face order) against the sequential order of the same kernels: the six matrices
+    and A bit for bit, on a rebuilt-topology call with kept patterns and on a values-only call."""
+    M = pa._lib
+    keys = (M.MAT_FLUX, M.MAT_BOUND_FLUX, M.MAT_BOUND_PRESSURE_CELL, M.MAT_BOUND_PRESSURE_FACE, M.MAT_VECTOR_SOURCE,
+            M.MAT_BOUND_PRESSURE_VECTOR_SOURCE)
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.2 / n)
+    rng = np.random.default_rng(5)
+    sc = np.exp(0.6 * rng.standard_normal(g.num_cells))
+    K = pa.SecondOrderTensor(kxx=sc, kyy=4 * sc, kzz=0.3 * sc, kxy=0.3 * sc, kyz=0.1 * sc)
+    bf = g.get_all_boundary_faces()
+    flags = np.zeros(g.num_faces, dtype=np.uint8)
+    flags[bf] = 2
+    flags[bf[g.face_centers[0, bf] < 1e-9]] = 1
+    raw = pa.grid_to_raw(g)
+    saved = {k: os.environ.get(k) for k in ("PFV_PIPE", "PFV_PIPE_MIN_FACES", "PFV_PIPE_CHUNKS")}
+    out = {}
+    try:
+        os.environ["PFV_PIPE_MIN_FACES"] = "0"
+        for mode, chunks in (("0", "8"), ("1", "8"), ("1", "3")):
+            os.environ["PFV_PIPE"] = mode
+            os.environ["PFV_PIPE_CHUNKS"] = chunks
+            ctx = pa.Context(0, lib)
+            ctx.set_grid(raw)
+            ctx.set_params(np.ascontiguousarray(K.values), flags, None, 1.0 / 3.0)
+            ctx.discretize(rebuild_topology=True)        # first call: the patterns are built beside the node kernel
+            runs = [int(ctx.stats()["pipeline_runs"])]
+            ctx.discretize(rebuild_topology=True)        # patterns kept: the pipeline (when on)
+            runs.append(int(ctx.stats()["pipeline_runs"]))
+            mats = [ctx.matrix(k) for k in keys]
+            ctx.discretize()                             # values only: the pipeline too
+            runs.append(int(ctx.stats()["pipeline_runs"]))
+            mats2 = [ctx.matrix(k) for k in keys]
+            ctx.assemble(np.zeros(g.num_faces), None, g.cell_volumes)
+            mats.append(ctx.matrix(M.MAT_SYSTEM))
+            out[(mode, chunks)] = (runs, mats, mats2)
+            ctx.close()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    base = out[("0", "8")]
+    assert base[0] == [0, 0, 0]
+    for key in (("1", "8"), ("1", "3")):
+        runs, mats, mats2 = out[key]
+        if device:
+            assert runs == [0, int(key[1]), int(key[1])], runs
+        for a, b in zip(mats, base[1]):
+            assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data)
+        for a, b in zip(mats2, base[2]):
+            assert np.array_equal(a.data, b.data)
+    return True

@@ -142,6 +142,11 @@ def test_rebuilt_topology_keeps_the_patterns_it_proves_unchanged(lib):
     assert P.symbolic_reuse_on_rebuilt_topology(lib)
 
 
+def test_ready_run_major_face_order_leaves_the_same_matrices(lib):
+    # (the host build has no second stream: what is pinned here is the face order the pipeline's topology produces)
+    assert P.node_face_pipeline_leaves_the_same_bits(lib, 8, device=False)
+
+
 @pytest.mark.parametrize("name", ["partial_cart2d_5x5", "partial_tet3d_3x3x3"])
 def test_partial_discretization_and_update(lib, name):
     P.check_partial_case(lib, name)

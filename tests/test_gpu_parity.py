@@ -80,6 +80,10 @@ def test_rebuilt_topology_keeps_the_patterns_it_proves_unchanged(lib):
     assert P.symbolic_reuse_on_rebuilt_topology(lib, n=10)
 
 
+def test_node_face_pipeline_leaves_the_bits_of_the_sequential_order(lib):
+    assert P.node_face_pipeline_leaves_the_same_bits(lib, 16, device=True)
+
+
 def test_config_c2_scale_properties(lib):
     """BASELINE config 2 (196 608 tetrahedra): exact linear field, zero flux for constant
     pressure — size-independent properties; the oracle is too slow at this size."""
