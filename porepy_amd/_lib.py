@@ -840,6 +840,27 @@ class Context:
         import scipy.sparse as sps
 
         nrows, ncols, nnz = self.matrix_info(which)
+        if which in (MAT_VECTOR_SOURCE, MAT_BOUND_PRESSURE_VECTOR_SOURCE) and (
+                nnz >= 2 ** 31 or os.environ.get("PFV_VS_IMPLICIT", "0") not in ("", "0")):
+            # beyond 2^31 entries (nd x the flux pattern: ~6.3 M tetrahedra) the handle keeps no int32 CSR arrays of the two
+            # vector-source matrices (csrc/topology.inc: vs_implicit): fetched in row chunks, joined with int64 row pointers
+            # (scipy widens its index arrays by itself)
+            want = None if rows is None else np.unique(np.asarray(rows, dtype=np.int64))
+            step = max(1, int(2 ** 29 // max(1, nnz // max(nrows, 1))))
+            parts, ptr = [], [np.zeros(1, dtype=np.int64)]
+            for r0 in range(0, nrows, step):
+                r1 = min(nrows, r0 + step)
+                rr = np.arange(r0, r1) if want is None else want[(want >= r0) & (want < r1)]
+                lens = np.zeros(r1 - r0, dtype=np.int64)
+                if rr.size:
+                    M = self.matrix_rows(which, rr)
+                    parts.append((M.indices.astype(np.int64 if ncols >= 2 ** 31 else np.int32), M.data))
+                    lens[rr - r0] = np.diff(M.indptr)
+                ptr.append(ptr[-1][-1] + np.cumsum(lens))
+            indptr = np.concatenate(ptr)
+            indices = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int32)
+            data = np.concatenate([p[1] for p in parts]) if parts else np.zeros(0)
+            return sps.csr_matrix((data, indices, indptr), shape=(nrows, ncols))
         pool = pinned_pool(self.lib)  # page-locked blocks, recycled from the matrices that were collected
         indptr = pool.empty(nrows + 1, np.int32)
         indices = pool.empty(nnz, np.int32)

@@ -186,6 +186,10 @@ struct pfv_ctx_impl {
   bool rows_complete = false;  // every row of the six MPFA matrices holds a discretization (maybe of older parameters)
   CsrPattern pat_flux, pat_bound, pat_vs, pat_A;  // bound_pressure_* share flux / bound patterns
   bool vs_indices_pending = false;  // pat_vs.indices not written yet (topology.inc: ensure_vs_indices)
+  bool vs_implicit = false;         // vector_source / bound_pressure_vector_source have >= 2^31 entries (nd x the flux pattern:
+                                    // beyond ~6.3 M tetrahedra): their int32 row pointers and indices are never formed -- the
+                                    // values are addressed through the flux pattern (entry p, component k -> nd p + k, 64-bit),
+                                    // products take spmv_vs_implicit, exports go by rows (pfv_get_matrix_rows)
   Buf<double> val[PFV_NUM_MATS];
   bool filled[PFV_NUM_MATS] = {};
   Buf<double> rhs, diag, xsol, face_tmp, vec_in;

@@ -697,6 +697,9 @@ pfv_status pfv_get_matrix(pfv_ctx* h, int which, int32_t* indptr, int32_t* indic
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
     require(pattern_ready(h, which), "discretize first");
+    if ((which == PFV_MAT_VECTOR_SOURCE || which == PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE) && h->vs_implicit && !h->tpfa_mode)
+      throw pfv::Error(PFV_ERR_UNSUPPORTED, "vector_source has more than 2^31 entries on this handle: int32 CSR arrays "
+                                            "cannot hold it -- fetch it by rows (pfv_get_matrix_rows)");
     if (indices) materialize_pattern(h, which);
     const pfv::CsrPattern& P = h->pattern_of(which);
     auto s = h->stream;
@@ -715,8 +718,12 @@ pfv_status pfv_get_matrix_rows(pfv_ctx* h, int which, int64_t n_rows, const int3
     require(which >= 0 && which < PFV_NUM_MATS, "bad matrix selector");
     require(pattern_ready(h, which), "discretize first");
     require(n_rows >= 0 && (n_rows == 0 || rows) && out_indptr, "bad row list");
-    if (out_indices || out_data) materialize_pattern(h, which);
-    const pfv::CsrPattern& P = h->pattern_of(which);
+    // (vector-source matrices beyond 2^31 entries: rows are expanded from the flux pattern, nd entries per flux entry)
+    const bool imp = (which == PFV_MAT_VECTOR_SOURCE || which == PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE) && h->vs_implicit &&
+                     !h->tpfa_mode;
+    const int mult = imp ? h->nd : 1;
+    if (!imp && (out_indices || out_data)) materialize_pattern(h, which);
+    const pfv::CsrPattern& P = imp ? h->pat_flux : h->pattern_of(which);
     for (int64_t i = 0; i < n_rows; ++i) require(rows[i] >= 0 && rows[i] < P.nrows, "row index out of range");
     auto s = h->stream;
     pfv::Buf<int32_t> d_rows, d_len, d_ix;
@@ -727,7 +734,7 @@ pfv_status pfv_get_matrix_rows(pfv_ctx* h, int which, int64_t n_rows, const int3
     int64_t* dp = d_ptr.ensure(n_rows + 1);
     be_h2d(dr, rows, sizeof(int32_t) * (size_t)n_rows, s);
     const int32_t* ip = P.indptr;
-    pfv::parallel_for(s, n_rows, PFV_LAMBDA(int64_t i) { dl[i] = ip[dr[i] + 1] - ip[dr[i]]; });
+    pfv::parallel_for(s, n_rows, PFV_LAMBDA(int64_t i) { dl[i] = (ip[dr[i] + 1] - ip[dr[i]]) * mult; });
     pfv::exclusive_scan<int32_t, int64_t>(s, h->scratch, dl, dp, (size_t)n_rows);
     std::vector<int64_t> hp((size_t)n_rows + 1);
     be_d2h(hp.data(), dp, sizeof(int64_t) * (size_t)(n_rows + 1), s);
@@ -744,9 +751,17 @@ pfv_status pfv_get_matrix_rows(pfv_ctx* h, int which, int64_t n_rows, const int3
       const int64_t i = w.item;
       const int p0 = ip[dr[i]], len = dl[i];
       const int64_t o = dp[i];
-      PFV_LANES(k, len) {
-        tix[o + k] = ix[p0 + k];
-        if (val) tv[o + k] = val[p0 + k];
+      if (mult == 1) {
+        PFV_LANES(k, len) {
+          tix[o + k] = ix[p0 + k];
+          if (val) tv[o + k] = val[p0 + k];
+        }
+      } else {
+        PFV_LANES(k, len) {
+          const int e = k / mult, cpt = k - e * mult;
+          tix[o + k] = ix[p0 + e] * mult + cpt;
+          if (val) tv[o + k] = val[(int64_t)p0 * mult + k];
+        }
       }
     });
     if (out_indices) be_d2h(out_indices, tix, sizeof(int32_t) * (size_t)tot, s);
@@ -1329,14 +1344,16 @@ pfv_status pfv_spmv(pfv_ctx* h, int which, const double* x, double* y) {
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS && x && y, "bad argument");
     require((h->have_symbolic || which == PFV_MAT_USER_SYSTEM) && h->filled[which], "matrix values have not been computed");
-    materialize_pattern(h, which);
+    const bool vs = which == PFV_MAT_VECTOR_SOURCE || which == PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE;
+    if (!(vs && h->vs_implicit)) materialize_pattern(h, which);
     const pfv::CsrPattern& P = h->pattern_of(which);
     auto s = h->stream;
     pfv::Buf<double> dx, dy;
     dx.ensure((size_t)P.ncols);
     dy.ensure((size_t)P.nrows);
     be_h2d(dx.p, x, sizeof(double) * (size_t)P.ncols, s);
-    pfv::spmv(*h, P, h->val[which], dx.p, dy.p);
+    if (vs && h->vs_implicit) pfv::spmv_vs_implicit(*h, h->val[which], dx.p, dy.p);
+    else pfv::spmv(*h, P, h->val[which], dx.p, dy.p);
     be_d2h(y, dy.p, sizeof(double) * (size_t)P.nrows, s);
   });
 }
@@ -1345,6 +1362,10 @@ pfv_status pfv_spmv_device(pfv_ctx* h, int which, const double* d_x, double* d_y
   return guarded(h, [&] {
     require(which >= 0 && which < PFV_NUM_MATS && d_x && d_y, "bad argument");
     require((h->have_symbolic || which == PFV_MAT_USER_SYSTEM) && h->filled[which], "matrix values have not been computed");
+    if ((which == PFV_MAT_VECTOR_SOURCE || which == PFV_MAT_BOUND_PRESSURE_VECTOR_SOURCE) && h->vs_implicit) {
+      pfv::spmv_vs_implicit(*h, h->val[which], d_x, d_y);
+      return;
+    }
     materialize_pattern(h, which);
     pfv::spmv(*h, h->pattern_of(which), h->val[which], d_x, d_y);
   });

@@ -2473,3 +2473,73 @@ def node_face_pipeline_leaves_the_same_bits(lib, n=16, device=True):
         for a, b in zip(mats2, base[2]):
             assert np.array_equal(a.data, b.data)
     return True
+
+
+def implicit_vector_source_pattern(lib, n=4):
+    """Beyond 2^31 entries (~6.3 M tetrahedra on one handle) the two vector-source matrices keep no CSR arrays of their own:
+    values addressed through the flux pattern, products by ``spmv_vs_implicit``, exports by rows.  ``PFV_VS_IMPLICIT=1``
+    forces that form at any size: every route must return what the explicit form returns -- exported matrices bit for
+    bit (whole and by rows), the product and the right-hand side with a vector source to rounding; the whole-matrix C
+    export is refused with the message that names the row export."""
+    M = pa._lib
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.03)
+    rng = np.random.default_rng(8)
+    sc = np.exp(0.5 * rng.standard_normal(g.num_cells))
+    K = pa.SecondOrderTensor(kxx=sc, kyy=2 * sc, kzz=0.4 * sc, kxy=0.2 * sc, kxz=0.1 * sc)
+    bf = g.get_all_boundary_faces()
+    flags = np.zeros(g.num_faces, dtype=np.uint8)
+    flags[bf] = 2
+    flags[bf[g.face_centers[2, bf] < 1e-9]] = 1
+    raw = pa.grid_to_raw(g)
+    gvec = rng.standard_normal(3 * g.num_cells)
+    bv = rng.standard_normal(g.num_faces) * (flags > 0)
+    out = {}
+    saved = os.environ.get("PFV_VS_IMPLICIT")
+    try:
+        for mode in ("0", "1"):
+            os.environ["PFV_VS_IMPLICIT"] = mode
+            ctx = pa.Context(0, lib)
+            ctx.set_grid(raw)
+            ctx.set_params(np.ascontiguousarray(K.values), flags, None, 1.0 / 3.0)
+            ctx.discretize()
+            vs = ctx.matrix(M.MAT_VECTOR_SOURCE)
+            bpvs = ctx.matrix(M.MAT_BOUND_PRESSURE_VECTOR_SOURCE)
+            some = np.array([0, 3, g.num_faces - 1, 7])
+            part = ctx.matrix_rows(M.MAT_VECTOR_SOURCE, some)
+            only = ctx.matrix(M.MAT_VECTOR_SOURCE, rows=some)
+            y = ctx.spmv(M.MAT_VECTOR_SOURCE, gvec) if hasattr(ctx, "spmv") else None
+            ctx.assemble(bv, gvec, g.cell_volumes)
+            b = ctx.rhs()
+            if mode == "1":
+                nnz = ctx.matrix_info(M.MAT_VECTOR_SOURCE)[2]
+                ip = np.zeros(g.num_faces + 1, np.int32)
+                ix = np.zeros(nnz, np.int32)
+                dv = np.zeros(nnz)
+                with pytest_raises(pa.PorefvError) as e:
+                    ctx._check(ctx.lib.pfv_get_matrix(ctx._h, M.MAT_VECTOR_SOURCE, M._ptr(ip, M._ip), M._ptr(ix, M._ip), M._ptr(dv, M._dp)))
+                assert "pfv_get_matrix_rows" in str(e.value)
+            out[mode] = (vs, bpvs, part, only, y, b)
+            ctx.close()
+    finally:
+        if saved is None:
+            os.environ.pop("PFV_VS_IMPLICIT", None)
+        else:
+            os.environ["PFV_VS_IMPLICIT"] = saved
+    a, b = out["0"], out["1"]
+    for i in range(4):
+        assert a[i].shape == b[i].shape
+        assert np.array_equal(a[i].indptr, b[i].indptr) and np.array_equal(a[i].indices, b[i].indices)
+        assert np.array_equal(a[i].data, b[i].data)
+    if a[4] is not None:
+        assert np.linalg.norm(a[4] - b[4]) <= 1e-14 * np.linalg.norm(a[4])
+    assert np.linalg.norm(a[5] - b[5]) <= 1e-13 * np.linalg.norm(a[5])
+    assert np.linalg.norm(a[5] - (g.cell_volumes - g.cell_faces.T @ (0 * bv))) > 0  # (the vector source did reach the rhs)
+    return True
+
+
+def pytest_raises(exc):
+    import pytest
+
+    return pytest.raises(exc)

@@ -138,6 +138,10 @@ def test_rediscretize_with_new_parameters_reuses_topology(lib):
     assert d.context(g).stats()["num_sub_half_faces"] == st1["num_sub_half_faces"]
 
 
+def test_vector_source_matrices_addressed_through_the_flux_pattern(lib):
+    assert P.implicit_vector_source_pattern(lib)
+
+
 def test_rebuilt_topology_keeps_the_patterns_it_proves_unchanged(lib):
     assert P.symbolic_reuse_on_rebuilt_topology(lib)
 

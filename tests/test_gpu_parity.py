@@ -74,6 +74,10 @@ def test_deterministic_bitwise(lib):
         assert np.array_equal(a.data, b.data), k
 
 
+def test_vector_source_matrices_addressed_through_the_flux_pattern(lib):
+    assert P.implicit_vector_source_pattern(lib)
+
+
 def test_rebuilt_topology_keeps_the_patterns_it_proves_unchanged(lib):
     # (the device path runs the interaction-region kernel alone when the patterns are kept, beside the symbolic phase
     # otherwise: both orders of events must leave the bits of a cold handle)
