@@ -505,6 +505,38 @@ def value_digest(M, n_blocks: int = N_BLOCKS, rows_mask=None):
     return out
 
 
+FINE_ROWS = 256  # rows per block of the fine digest (the 1 024 blocks of value_digest hold 3 878 rows on the headline grid)
+
+
+def fine_digest(M, rows_mask=None, rows_per: int = FINE_ROWS):
+    """Per block of ``rows_per`` consecutive rows: sum |a| and max |a| (a block sum over 3 878 rows x 56
+    entries within 1e-13 still lets one entry be off by 2e-8 of a mean entry; 256-row blocks are 15 x tighter, and the
+    maximum pins the largest entry of every block on its own).  Same function for the reference's fixture
+    (oracle/gen_golden_headline_fine.py) and for the device's matrices."""
+    import scipy.sparse as sps
+
+    M = sps.csr_matrix(M)
+    n = M.shape[0]
+    nb = -(-n // rows_per)
+    out = np.zeros((2, nb))
+    indptr = np.asarray(M.indptr, dtype=np.int64)
+    mask = None if rows_mask is None else np.asarray(rows_mask, bool)
+    step = 1 << 18
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        e0, e1 = int(indptr[r0]), int(indptr[r1])
+        if e1 == e0:
+            continue
+        row_of = np.repeat(np.arange(r0, r1, dtype=np.int64), np.diff(indptr[r0:r1 + 1]))
+        a = np.abs(np.asarray(M.data[e0:e1], dtype=float))
+        if mask is not None:
+            a = np.where(mask[row_of], a, 0.0)
+        blk = row_of // rows_per
+        out[0] += np.bincount(blk, weights=a, minlength=nb)
+        np.maximum.at(out[1], blk, a)
+    return out
+
+
 def vector_digest(x, n_blocks: int = N_BLOCKS):
     """Per block of consecutive entries: sum x, sum x^2."""
     x = np.asarray(x, dtype=float)
@@ -514,7 +546,7 @@ def vector_digest(x, n_blocks: int = N_BLOCKS):
 
 
 def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_pattern: bool = False, n_side: int = 69,
-                     library=None, fixture: str | None = None):
+                     library=None, fixture: str | None = None, fine_fixture: str | None = None):
     """Whole-grid parity datum at the headline size.  The REFERENCE was run on all 1 971 054
     tetrahedra of make_problem(69) (``oracle/gen_golden_headline_pattern.py``: pp.Mpfa with 12 sub-problems, 20 minutes
     of host time; the same topology and geometry arrays the device gets) and left, in
@@ -547,6 +579,28 @@ def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_patt
                 Mx = ctx.matrix(which)
                 more[name] = value_digest(Mx, z[name + "_value_digest"].shape[1], rows_mask=msk)
                 del Mx
+        # fine datum of a second run of the reference on the same grid (round 6: oracle/gen_golden_headline_fine.py): per
+        # block of 256 rows sum |a| and max |a| of all six matrices
+        fine = {}
+        fpath = fine_fixture or HEADLINE_PATTERN.replace("headline_flux_pattern_", "headline_fine_digest_").replace("_69.npz", f"_{n_side}.npz")
+        if os.path.exists(fpath) and (fixture is None or fine_fixture is not None):
+            zf = np.load(fpath)
+            for name, which, msk in (("flux", pa._lib.MAT_FLUX, ~neu), ("bound_flux", pa._lib.MAT_BOUND_FLUX, None),
+                                     ("bound_pressure_cell", pa._lib.MAT_BOUND_PRESSURE_CELL, None),
+                                     ("bound_pressure_face", pa._lib.MAT_BOUND_PRESSURE_FACE, None),
+                                     ("vector_source", pa._lib.MAT_VECTOR_SOURCE, ~neu),
+                                     ("bound_pressure_vector_source", pa._lib.MAT_BOUND_PRESSURE_VECTOR_SOURCE, None)):
+                if name + "_fine" not in zf.files:
+                    continue
+                Mx = F if name == "flux" else ctx.matrix(which)
+                dev, ref = fine_digest(Mx, rows_mask=msk), zf[name + "_fine"]
+                if name != "flux":
+                    del Mx
+                gscale = float(np.max(ref[1]))  # (largest entry of the matrix: blocks of boundary rows hold tiny sums)
+                sc0 = np.maximum(ref[0], 1e-6 * gscale)
+                fine[name] = {"blocks": int(ref.shape[1]),
+                              "sum_abs_worst_rel_diff": float(np.max(np.abs(dev[0] - ref[0]) / sc0)),
+                              "max_abs_worst_rel_diff": float(np.max(np.abs(dev[1] - ref[1]) / np.maximum(ref[1], 1e-6 * gscale)))}
         nnz_sys = int(ctx.matrix_info(pa._lib.MAT_SYSTEM)[2])
     finally:
         ctx.close()
@@ -591,6 +645,8 @@ def whole_grid_check(pa, device_index: int, rtol: float, precond: str, want_patt
             np.max(np.abs(pd[0] - pr[0]) / np.maximum(np.sqrt(pr[1] * np.maximum(1, -(-x.size // pr.shape[1]))), 1e-300)))
         out["values_vs_reference"]["pressure_block_squares_worst_rel_diff"] = float(
             np.max(np.abs(pd[1] - pr[1]) / np.maximum(pr[1], 1e-300)))
+    if fine:
+        out["fine_values_vs_reference"] = {"rows_per_block": FINE_ROWS, **fine}
     if want_pattern:
         out["_pattern"] = (F.indptr, F.indices, ~neu, int(z["digest_rows"][0]))
     return out

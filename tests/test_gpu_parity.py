@@ -422,6 +422,15 @@ def test_whole_headline_grid_pattern_against_the_reference_run_on_the_whole_grid
     for k in ("bound_pressure_cell", "bound_pressure_face", "vector_source", "bound_pressure_vector_source"):
         if k + "_worst_rel_diff_abs_sq_weighted" in v:
             assert max(v[k + "_worst_rel_diff_abs_sq_weighted"]) < 1e-13, (k, v[k + "_worst_rel_diff_abs_sq_weighted"])
+    # ... and the FINE datum of a second run of the reference on the same grid (round 6, oracle/gen_golden_headline_fine.py):
+    # per block of 256 rows (15 511 blocks) sum |a| and max |a| of all six matrices -- the largest entry of every block
+    # pinned on its own, the block sums 15 x tighter than above
+    fine = out.get("fine_values_vs_reference")
+    assert fine is not None and fine["rows_per_block"] == 256, "tests/golden/headline_fine_digest_69.npz missing"
+    print("whole-grid fine values vs reference:", fine)
+    for k in ("flux", "bound_flux", "bound_pressure_cell", "bound_pressure_face", "vector_source", "bound_pressure_vector_source"):
+        assert fine[k]["blocks"] == 15511, (k, fine[k])
+        assert fine[k]["sum_abs_worst_rel_diff"] < 1e-12 and fine[k]["max_abs_worst_rel_diff"] < 1e-12, (k, fine[k])
 
 
 def test_config_c2_all_matrices_on_patches(lib):

@@ -310,7 +310,18 @@ def test_whole_grid_datum_machinery_on_a_small_grid(tmp_path):
     from oracle.gen_golden_headline_pattern import headline_digest
     from tests import _parity as P
 
-    out = bench.whole_grid_check(pa, 0, 1e-13, "amg", want_pattern=True, n_side=8, library=P.emulation_library(), fixture=fx)
+    # (round 6: the fine datum -- 256-row blocks, sum |a| and max |a| of all six matrices -- by its own generator)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden_headline_fine.py"), "8", "2", str(tmp_path)],
+                        env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+    fx2 = os.path.join(str(tmp_path), "headline_fine_digest_8.npz")
+    assert os.path.exists(fx2), r2.stderr[-2000:]
+    out = bench.whole_grid_check(pa, 0, 1e-13, "amg", want_pattern=True, n_side=8, library=P.emulation_library(), fixture=fx,
+                                 fine_fixture=fx2)
+    fine = out["fine_values_vs_reference"]
+    assert fine["rows_per_block"] == 256 and len([k for k in fine if k != "rows_per_block"]) == 6
+    for k, d in fine.items():
+        if k != "rows_per_block":
+            assert d["sum_abs_worst_rel_diff"] < 1e-12 and d["max_abs_worst_rel_diff"] < 1e-12, (k, d)
     indptr, indices, rows, ref_digest = out.pop("_pattern")
     assert out["pattern_row_lengths_equal"] and headline_digest(indptr, indices, rows) == ref_digest
     v = out["values_vs_reference"]
