@@ -139,6 +139,8 @@ typedef struct {
                                      differ by more than PFV_MPSA_CONTRAST_LIMIT (1e6) -- the regions that were assembled and
                                      eliminated in double-double arithmetic (mpsa_dd.inc) */
   double mpsa_max_contrast;       /* MPSA: the largest such ratio over all interaction regions (1: homogeneous) */
+  int64_t assemble_positions_kept; /* 1: the last div @ flux replayed the positions of its entries recorded under the same
+                                      kept patterns (no column indices read, no searches); 0: searched */
   int64_t pipeline_runs;          /* > 0: the last pfv_mpfa_discretize ran the interaction-region kernel in this many runs on the
                                      second stream with the face kernel following run by run on the first (node_ms is then the
                                      span of the whole pipeline, face_ms what came after it); 0: one after the other */

@@ -65,7 +65,8 @@ class Stats(C.Structure):
                 ("win_reused", C.c_int64), ("amg_filter_layout", C.c_int64),
                 ("solve_launches", C.c_int64), ("amg_setup_launches", C.c_int64), ("node_redo", C.c_int64),
                 ("symbolic_reused", C.c_int64), ("amg_stale_rematches", C.c_int64),
-                ("mpsa_contrast_regions", C.c_int64), ("mpsa_max_contrast", C.c_double), ("pipeline_runs", C.c_int64)]
+                ("mpsa_contrast_regions", C.c_int64), ("mpsa_max_contrast", C.c_double), ("assemble_positions_kept", C.c_int64),
+                ("pipeline_runs", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -280,6 +280,9 @@ struct pfv_ctx_impl {
   unsigned long long win_rows_checksum = 0; // ... of the pattern whose leading win_rows_n rows win_rows covers
   unsigned long long symbolic_epoch = 0;  // bumped by every symbolic phase: saved AMG aggregates die with it
   unsigned long long topo_key = 0;   // topology_digest of the topology on the handle (0: not taken)
+  Buf<uint8_t> asm_pos, asm_diagpos;       // assemble_system: position in A's row of every flux entry of every (cell, face); diagonal
+  unsigned long long asm_pos_key = 0;      // ... the symb_key they were recorded under (0: none)
+  int64_t asm_pos_cells = 0;
   unsigned long long symb_key = 0;   // ... of the topology the symbolic outputs on the handle were built from (0: none / replaced)
   std::unique_ptr<BlockPc> block_pc;  // pfv_set_block_preconditioner
   std::unique_ptr<Amg> amg_block;    // pfv_amg_setup: hierarchy of the leading block (sharded solves)

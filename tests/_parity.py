@@ -2316,6 +2316,17 @@ def symbolic_reuse_on_rebuilt_topology(lib, n=4):
     cold.assemble(np.zeros(raw["face_centers"].shape[1]), None, raw["cell_volumes"])
     A1, A2 = ctx.matrix(M.MAT_SYSTEM), cold.matrix(M.MAT_SYSTEM)
     assert np.array_equal(A1.indices, A2.indices) and np.array_equal(A1.data, A2.data)
+    # div @ flux under kept patterns: the first assembly records where every flux entry lands in A's rows, the next ones
+    # replay the positions (device build; simplices / hexahedra) -- the same bits either way
+    ctx.discretize(rebuild_topology=True)
+    ctx.assemble(np.zeros(raw["face_centers"].shape[1]), None, raw["cell_volumes"])
+    st = ctx.stats()
+    assert st["symbolic_reused"] == 1
+    if lib.pfv_is_device_build() == 1:
+        assert st["assemble_positions_kept"] == 1, st
+    A3 = ctx.matrix(M.MAT_SYSTEM)
+    assert np.array_equal(A3.indices, A2.indices) and np.array_equal(A3.data, A2.data)
+    assert np.array_equal(ctx.rhs(), cold.rhs())
 
     # other condition TYPES on the same boundary: the patterns do not depend on them -> still kept
     _, _, flags_d = problem(n, 1, all_dir=True)
