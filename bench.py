@@ -668,13 +668,14 @@ def source_hash() -> str:
 def load_pmc(n_side: int, world: int) -> dict:
     """HBM traffic per launch from the PMC passes of tools/gpu_pmc.sh (FETCH_SIZE and WRITE_SIZE in separate
     runs), if profiles/ holds a file collected with exactly this build on this workload; else {}."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as fh:
-            pj = json.load(fh)
-        if pj.get("n_side") == n_side and world == 1 and pj.get("source_hash") == source_hash():
-            return pj["kernels"]
-    except Exception:
-        pass
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json"):  # (the newest file collected with THIS build wins)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                pj = json.load(fh)
+            if pj.get("n_side") == n_side and world == 1 and pj.get("source_hash") == source_hash():
+                return pj["kernels"]
+        except Exception:
+            pass
     return {}
 
 

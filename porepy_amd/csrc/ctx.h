@@ -283,6 +283,9 @@ struct pfv_ctx_impl {
   Buf<uint8_t> asm_pos, asm_diagpos;       // assemble_system: position in A's row of every flux entry of every (cell, face); diagonal
   unsigned long long asm_pos_key = 0;      // ... the symb_key they were recorded under (0: none)
   int64_t asm_pos_cells = 0;
+  Buf<uint8_t> asm_pos_m, asm_diagpos_m;   // the same for the mechanics system (mpsa.inc: mpsa_assemble_system)
+  unsigned long long asm_pos_m_key = 0;
+  int64_t asm_pos_m_rows = 0;
   unsigned long long symb_key = 0;   // ... of the topology the symbolic outputs on the handle were built from (0: none / replaced)
   std::unique_ptr<BlockPc> block_pc;  // pfv_set_block_preconditioner
   std::unique_ptr<Amg> amg_block;    // pfv_amg_setup: hierarchy of the leading block (sharded solves)

@@ -2554,3 +2554,44 @@ def pytest_raises(exc):
     import pytest
 
     return pytest.raises(exc)
+
+
+def mpsa_assemble_positions_replayed(lib, n=5):
+    """``div @ stress`` under kept patterns: the first assembly records the position of every stress entry in the rows of the
+    mechanics system, the following ones replay them (device build) -- same matrix, same right-hand side, bit for bit."""
+    g = pa.StructuredTetrahedralGrid([n, n, n], [1.0, 1.0, 1.0])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.04)
+    nc, nf = g.num_cells, g.num_faces
+    rng = np.random.default_rng(12)
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    for axis in range(3):
+        roll = bf[g.face_centers[axis, bf] < 1e-9]
+        bc.is_dir[axis, roll] = True
+        bc.is_neu[axis, roll] = False
+    bv = rng.standard_normal((3, nf)) * (bc.is_dir | bc.is_neu)
+    ctx = pa.Context(0, lib)
+    ctx.set_grid(pa.grid_to_raw(g))
+    out = []
+    for k in range(3):
+        C = pa.FourthOrderTensor(1.0 + rng.random(nc), 1.0 + rng.random(nc)) if k < 2 else C  # noqa: F821 (third = second field again)
+        ctx.mpsa_set_params(C.values, g.cell_volumes, bc.is_dir, bc.is_neu, 1.0 / 3.0)
+        ctx.mpsa_discretize(rebuild_topology=True)
+        ctx.mpsa_assemble(bv.ravel("F"), None)
+        out.append((ctx.matrix(pa._lib.MAT_MECH_SYSTEM), ctx.active_rhs(3 * nc), int(ctx.stats()["assemble_positions_kept"]),
+                    int(ctx.stats()["symbolic_reused"])))
+    ctx.close()
+    assert [o[3] for o in out] == [0, 1, 1]
+    if lib.pfv_is_device_build() == 1:
+        assert [o[2] for o in out] == [0, 1, 1], [o[2] for o in out]  # (the first assembly under the key records)
+    cold = pa.Context(0, lib)
+    cold.set_grid(pa.grid_to_raw(g))
+    cold.mpsa_set_params(C.values, g.cell_volumes, bc.is_dir, bc.is_neu, 1.0 / 3.0)
+    cold.mpsa_discretize()
+    cold.mpsa_assemble(bv.ravel("F"), None)
+    A0, b0 = cold.matrix(pa._lib.MAT_MECH_SYSTEM), cold.active_rhs(3 * nc)
+    cold.close()
+    for A, b, _, _ in out[1:]:
+        assert np.array_equal(A.indices, A0.indices) and np.array_equal(A.data, A0.data) and np.array_equal(b, b0)
+    return True

@@ -206,3 +206,7 @@ def test_stiffness_contrasts_of_1e8_to_1e12_between_neighbouring_cells(lib, name
 
 def test_the_fp64_body_alone_misses_the_contrast_fixtures(lib):
     assert P.mpsa_contrast_fp64_body_misses(lib) > 1e-9
+
+
+def test_mechanics_system_replays_its_positions_under_kept_patterns(lib):
+    assert P.mpsa_assemble_positions_replayed(lib)

@@ -430,7 +430,8 @@ def test_whole_headline_grid_pattern_against_the_reference_run_on_the_whole_grid
     print("whole-grid fine values vs reference:", fine)
     for k in ("flux", "bound_flux", "bound_pressure_cell", "bound_pressure_face", "vector_source", "bound_pressure_vector_source"):
         assert fine[k]["blocks"] == 15511, (k, fine[k])
-        assert fine[k]["sum_abs_worst_rel_diff"] < 1e-12 and fine[k]["max_abs_worst_rel_diff"] < 1e-12, (k, fine[k])
+        # (observed: block sums <= 2.7e-15, block maxima <= 6.1e-14)
+        assert fine[k]["sum_abs_worst_rel_diff"] < 1e-13 and fine[k]["max_abs_worst_rel_diff"] < 1e-12, (k, fine[k])
 
 
 def test_config_c2_all_matrices_on_patches(lib):

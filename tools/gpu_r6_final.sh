@@ -35,7 +35,7 @@ e = oracle.ref_env(extra_last=["."], prefer_archive=True)
 print(e["PYTHONPATH"] if e else "")
 PY
 )
-if [ -n "$ENVF" ]; then
+if [ -n "$ENVF" ] && [ -z "${SKIP_FUZZ:-}" ]; then
   (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH="$ENVF:$R" timeout 600 python $R/tools/fuzz_vs_reference.py 40 918273 > $R/$O/fuzz_device_vs_reference.log 2>&1; tail -2 $R/$O/fuzz_device_vs_reference.log)
   (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH="$ENVF:$R" timeout 600 python $R/tools/fuzz_vs_reference.py 30 555111 special > $R/$O/fuzz_device_vs_reference_special.log 2>&1; tail -2 $R/$O/fuzz_device_vs_reference_special.log)
   (cd /tmp && PFV_FUZZ_DEVICE=1 PYTHONDONTWRITEBYTECODE=1 PYTHONPATH="$ENVF:$R" timeout 600 python $R/tools/fuzz_vs_reference.py 40 7000 contrast > $R/$O/fuzz_device_vs_reference_contrast.log 2>&1; tail -2 $R/$O/fuzz_device_vs_reference_contrast.log)
