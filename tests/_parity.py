@@ -2595,3 +2595,35 @@ def mpsa_assemble_positions_replayed(lib, n=5):
     for A, b, _, _ in out[1:]:
         assert np.array_equal(A.indices, A0.indices) and np.array_equal(A.data, A0.data) and np.array_equal(b, b0)
     return True
+
+
+def mpsa_singular_corner_is_an_error_not_a_fault(lib):
+    """Component-wise conditions that leave a rigid mode of a boundary region free make its local system singular (the
+    reference returns the inverse of rounding noise or raises; the differential driver classifies them "singular input").
+    On the device such a region fails the unpivoted check, goes to the double-double body, and its pivot columns turn into
+    NaNs after the zero pivot: the step must report "singular" (status 1) -- not index a row by the empty result of the
+    pivot search (round 6: a GPU memory fault found by the large device fuzz, fixed in gj_wide / node_gj_lds)."""
+    hits = 0
+    for seed in (3, 11, 17):  # (found by search: 3 x 3 Cartesian grid, Dirichlet / Neumann per component at random)
+        rng = np.random.default_rng(seed)
+        g = pa.CartGrid([3, 3], [1.0, 1.0])
+        g.compute_geometry()
+        nc = g.num_cells
+        bf = g.get_all_boundary_faces()
+        bc = pa.BoundaryConditionVectorial(g)
+        for a in range(2):
+            tdir = rng.random(bf.size) < 0.5
+            bc.is_dir[a, bf[tdir]] = True
+            bc.is_neu[a, bf[tdir]] = False
+            bc.is_neu[a, bf[~tdir]] = True
+        C = pa.FourthOrderTensor(np.ones(nc), np.ones(nc))
+        ctx = pa.Context(0, lib)
+        ctx.set_grid(pa.grid_to_raw(g))
+        ctx.mpsa_set_params(C.values, g.cell_volumes, bc.is_dir, bc.is_neu, 0.0)
+        try:
+            ctx.mpsa_discretize()
+        except pa.PorefvError as e:
+            hits += int(e.status == 1)
+        ctx.close()
+    assert hits == 3, hits
+    return True

@@ -196,3 +196,7 @@ def test_the_fp64_body_alone_misses_the_contrast_fixtures(lib):
 
 def test_mechanics_system_replays_its_positions_under_kept_patterns(lib):
     assert P.mpsa_assemble_positions_replayed(lib)
+
+
+def test_singular_corner_region_is_reported_not_faulted(lib):
+    assert P.mpsa_singular_corner_is_an_error_not_a_fault(lib)
