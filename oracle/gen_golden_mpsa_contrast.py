@@ -29,9 +29,14 @@ from oracle.ref_bridge import grid_to_raw  # noqa: E402
 
 
 def exact_matrices(g, C, bc):
+    """2-D: every step of the node-local computation in 60-digit arithmetic from the FP64 inputs on (the exact answer to
+    the problem the inputs pose); 3-D: the FP64-assembled local systems inverted in 60 digits (object arrays of 216 x 216
+    per node are too slow) -- biased towards the reference's own assembly, see tools/fuzz_vs_reference.py: _exact_mechanics."""
     import mpmath as mp
 
     mp.mp.dps = 60
+    if g.dim == 2:
+        return so.discretize(grid_to_raw(g), C.values, {"is_dir": bc.is_dir, "is_neu": bc.is_neu}, real=mp.mpf)
     inv0, cond0 = np.linalg.inv, np.linalg.cond
     np.linalg.inv = lambda M: np.array((mp.matrix(M.tolist()) ** -1).tolist(), dtype=float)
     np.linalg.cond = lambda M: 1.0
@@ -49,7 +54,15 @@ def save_case(name, g, decades, rng, two_valued=True):
     """Fields drawn exactly as tools/fuzz_vs_reference.py: case_contrast draws them (mechanics leg)."""
     nc, nd = g.num_cells, g.dim
     bf = g.get_all_boundary_faces()
-    if two_valued:
+    if two_valued is None:  # exactly the driver's sequence of draws (case_contrast): field, coin, flow tensors, flow conditions
+        s = 10.0 ** (decades * (rng.random(nc) - 0.5))
+        if rng.random() < 0.5:
+            s = np.where(rng.random(nc) < 0.5, 10.0 ** (-decades / 2), 10.0 ** (decades / 2))
+        for _ in range(3 if nd == 2 else 6):
+            rng.random(nc)
+        rng.choice(["dir", "neu"], size=bf.size, p=[0.6, 0.4])
+        rng.integers(0, bf.size)
+    elif two_valued:
         s = np.where(rng.random(nc) < 0.5, 10.0 ** (-decades / 2), 10.0 ** (decades / 2))
     else:
         s = 10.0 ** (decades * (rng.random(nc) - 0.5))
@@ -96,6 +109,15 @@ def main():
         while kind >= 4:
             g, kind = random_ref_grid(rng)
         save_case(f"mpsacontrast_cart2d_5x5_1e{decades:.0f}", g, decades, rng)
+    # A perturbed triangle grid with a CONTINUOUS random field over 9 decades (seed 400023 of the driver's contrast mode):
+    # here the reference's FP64 ASSEMBLY of its gradient systems is what is off -- 4e-9 from the all-mpmath answer, as is the
+    # exact inverse of those FP64 systems -- while the double-double regions of the device are exact to 2e-16
+    rng = np.random.default_rng(400023)
+    g, kind = random_ref_grid(rng)
+    while kind >= 4:
+        g, kind = random_ref_grid(rng)
+    decades = rng.uniform(6.0, 10.0)
+    save_case("mpsacontrast_tri2d_seed400023_1e9", g, decades, rng, two_valued=None)
     # ... and a tetrahedral one on which it is the REFERENCE's FP64 inverse that is off (7e-7 at 1e12)
     rng = np.random.default_rng(20261001)
     g = perturb(pp.StructuredTetrahedralGrid([2, 1, 2], [1, 1, 1]), rng, 0.06)

@@ -91,3 +91,37 @@ def test_uniaxial_compression_is_exact():
     E, nu = 2.5, 0.25
     exact = np.vstack((nu * cc[0] / E, nu * cc[1] / E, -cc[2] / E))
     assert np.max(np.abs(u - exact)) < 1e-12
+
+
+def test_oracle_in_60_digit_arithmetic_agrees_with_its_fp64_self_on_a_benign_grid_and_not_at_high_contrast():
+    """``mpsa_oracle.discretize(real=mpmath.mpf)`` runs every step of the node-local computation in 60 digits from the FP64
+    inputs on: the arbiter the differential driver settles discrepancies against (round 6).  On a benign grid it agrees
+    with the FP64 oracle to rounding; on the reference-made fixture ``mpsacontrast_tri2d_seed400023_1e9`` the FP64 oracle
+    (and the reference, and the exact inverse of the FP64-assembled systems) is 4e-9 away from it -- the fixture's
+    ``exact_*`` matrices ARE this arbiter's."""
+    import mpmath as mp
+
+    import porepy_amd as pa
+    from oracle import mpsa_oracle as so
+    from tests._golden import MPSA_KEYS, MpsaContrastCase
+
+    mp.mp.dps = 60
+    g = pa.StructuredTriangleGrid([3, 2], [1.0, 1.0])
+    g.compute_geometry()
+    nc = g.num_cells
+    C = pa.FourthOrderTensor(1.0 + 0.1 * np.arange(nc), np.ones(nc))
+    bc = pa.BoundaryConditionVectorial(g)
+    bf = g.get_all_boundary_faces()
+    bc.is_dir[:, bf[::2]] = True
+    bc.is_neu[:, bf[::2]] = False
+    bc.is_neu[:, bf[1::2]] = True
+    cond = {"is_dir": bc.is_dir, "is_neu": bc.is_neu}
+    a = so.discretize(pa.grid_to_raw(g), C.values, cond)
+    b = so.discretize(pa.grid_to_raw(g), C.values, cond, real=mp.mpf)
+    for k in MPSA_KEYS:
+        assert abs(a[k] - b[k]).max() <= 1e-14 * abs(b[k]).max(), k
+    c = MpsaContrastCase("mpsacontrast_tri2d_seed400023_1e9")
+    fp64 = so.discretize(c.grid, c.stiffness, c.bc)
+    worst = max(abs(fp64[k] - c.exact[k]).max() / abs(c.exact[k]).max() for k in MPSA_KEYS)
+    assert 1e-9 < worst < 1e-7, worst                                   # (the FP64 formulation's own loss)
+    assert 1e-9 < max(c.ref_off_exact.values()) < 1e-7                  # (... which the reference shares)
