@@ -87,6 +87,7 @@ def discretize(
     bc: dict,
     eta: float | None = None,
     vector_dim: int | None = None,
+    real=None,
 ) -> dict:
     """MPFA-O discretization; returns the six matrices of the reference as csr.
 
@@ -94,6 +95,9 @@ def discretize(
     bc: dict with boolean arrays is_dir / is_neu / is_rob / is_internal (Nf,) and
         robin_weight (Nf,) — the fields of the reference's BoundaryCondition
         (params/bc.py:68-190).  Boundary values are given per face.
+    real: None = FP64 (numpy), as the reference; a scalar constructor (``mpmath.mpf``) = every arithmetic step of the
+        node-local computation in that type from the FP64 inputs on (object arrays, local inverse by mpmath): the exact
+        answer to the problem the inputs pose -- the arbiter of tools/fuzz_vs_reference.py (round 6; small grids).
     """
     nd = int(grid["dim"])
     if nd not in (2, 3):
@@ -124,6 +128,31 @@ def discretize(
     is_neu = np.asarray(bc["is_neu"], bool) | is_int
     rw = np.asarray(bc.get("robin_weight", np.ones(nbc)), dtype=float)
     fn_ptr_, fn_idx_ = grid["fn_indptr"], grid["fn_indices"]
+    perm = np.asarray(perm, dtype=float)
+    if real is not None:
+        import mpmath as _mp
+
+        def _conv(arr):
+            arr = np.asarray(arr, dtype=float)
+            out_ = np.empty(arr.shape, dtype=object)
+            flat, of = arr.ravel(), out_.ravel()
+            for i_ in range(flat.size):
+                of[i_] = real(float(flat[i_]))
+            return out_
+
+        nodes, fc, cc, fnrm, farea, perm, rw = (_conv(x) for x in (nodes, fc, cc, fnrm, farea, perm, rw))
+        eta = real(float(eta)) if np.ndim(eta) == 0 else _conv(eta)
+
+        def zeros(shape):
+            z = np.empty(shape, dtype=object)
+            z.fill(real(0))
+            return z
+
+        def invert(M):
+            return np.array((_mp.matrix(M.tolist()) ** -1).tolist(), dtype=object).reshape(M.shape)
+    else:
+        zeros = np.zeros
+        invert = None
 
     node_start = np.flatnonzero(np.r_[True, h_v[1:] != h_v[:-1], True])
     acc = {k: ([], [], []) for k in MATRIX_KEYS}
@@ -145,9 +174,15 @@ def discretize(
         m = nd * deg
         # geometry per sub-half-face
         n_h = fnrm[:nd, hf] / nn_face[hf]  # (nd, nh), stored orientation
-        nK = np.einsum("ih,ijh->jh", n_h, perm[:nd, :nd, hc])  # n^T K -> (nd, nh)
+        if real is None:
+            nK = np.einsum("ih,ijh->jh", n_h, perm[:nd, :nd, hc])  # n^T K -> (nd, nh)
+        else:
+            nK = zeros((nd, nh))
+            for h_ in range(nh):
+                for j_ in range(nd):
+                    nK[j_, h_] = sum(n_h[i_, h_] * perm[i_, j_, hc[h_]] for i_ in range(nd))
         if np.ndim(eta) == 0:
-            eta_h = np.where(is_bnd_face[hf], 0.0, eta)  # scalar: forced to 0 on the boundary (_fvutils.py:257-268)
+            eta_h = np.where(is_bnd_face[hf], 0.0 if real is None else real(0), eta)  # scalar: forced to 0 on the boundary (_fvutils.py:257-268)
         else:
             eta_h = np.asarray(eta, float)[subface_ids(grid, hf, v)]  # one value per sub-face, used as given
         fch = fc[:nd, hf]
@@ -181,12 +216,12 @@ def discretize(
         nF, nR, nP = len(rows_F), len(rows_R), len(rows_P)
         if nF + nR + nP != m:
             raise ValueError("local system is not square")
-        G = np.zeros((m, m))
-        Rc = np.zeros((m, deg))  # cell-pressure right-hand side
+        G = zeros((m, m))
+        Rc = zeros((m, deg))  # cell-pressure right-hand side
         bfaces = [s for s in range(nsf) if is_bnd_face[faces[s]]]
         bcol = {s: i for i, s in enumerate(bfaces)}
-        Rb = np.zeros((m, len(bfaces)))
-        E = np.zeros((m, deg * nd))  # vector-source right-hand side, column nd*j+k
+        Rb = zeros((m, len(bfaces)))
+        E = zeros((m, deg * nd))  # vector-source right-hand side, column nd*j+k
         row_of = {}
         for r, s in enumerate(rows_F):
             row_of[("F", s)] = r
@@ -221,24 +256,27 @@ def discretize(
         scale = 1.0 / np.abs(G).sum(axis=1)
         try:
             Gs = scale[:, None] * G
-            if np.linalg.cond(Gs) > 1e14:  # singular up to rounding: the reference's LAPACK inverse raises on these
-                raise np.linalg.LinAlgError("Singular matrix")
-            igrad = np.linalg.inv(Gs) * scale[None, :]
-        except np.linalg.LinAlgError as exc:  # matrix_operations.py:1487-1490
+            if invert is not None:
+                igrad = invert(Gs) * scale[None, :]
+            else:
+                if np.linalg.cond(Gs) > 1e14:  # singular up to rounding: the reference's LAPACK inverse raises on these
+                    raise np.linalg.LinAlgError("Singular matrix")
+                igrad = np.linalg.inv(Gs) * scale[None, :]
+        except (np.linalg.LinAlgError, ZeroDivisionError) as exc:  # matrix_operations.py:1487-1490
             raise ValueError("Error in inversion of local linear systems") from exc
 
         # first-sorted side of every subface = the side fluxes are evaluated from
         first_h = np.full(nsf, -1)
         for h in range(nh - 1, -1, -1):
             first_h[sloc[h]] = h
-        W = np.zeros((nsf, m))  # Darcy rows: -nK on the subcell of h*
+        W = zeros((nsf, m))  # Darcy rows: -nK on the subcell of h*
         for s in range(nsf):
             h = first_h[s]
             W[s, col0[h] : col0[h] + nd] = -nK[:, h]
         # trace rows: average over the sides of the subface of p_c + d_h . g
         nsides = np.bincount(sloc, minlength=nsf)
-        D = np.zeros((nsf, m))
-        Dc = np.zeros((nsf, deg))
+        D = zeros((nsf, m))
+        Dc = zeros((nsf, deg))
         for h in range(nh):
             s = sloc[h]
             D[s, col0[h] : col0[h] + nd] += d_h[:, h] / nsides[s]
@@ -252,7 +290,7 @@ def discretize(
         t_cell, t_bnd, t_vs = Di @ Rc + Dc, Di @ Rb, Di @ E
 
         wf = 1.0 / nn_face[faces]  # subface -> face averaging of traces
-        wrow = np.ones(nsf) if subface_bc else wf
+        wrow = (np.ones(nsf) if real is None else np.array([real(1)] * nsf, dtype=object)) if subface_bc else wf
         rid = sfid if subface_bc else faces
         frow = np.repeat(rid, deg)
         ccol = np.tile(cells, nsf)
