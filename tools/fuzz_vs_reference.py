@@ -444,6 +444,12 @@ def _classify_with_exact_inverse(g, C, vb, ref_mats=None):
         return "regular"
     except ZeroDivisionError:
         return "singular"
+    except ValueError as e:
+        # (the oracle reports an exactly singular 60-digit inverse the way the reference reports LAPACK's: ValueError
+        # chained to the ZeroDivisionError of mpmath's LU)
+        if isinstance(e.__cause__, ZeroDivisionError):
+            return "singular"
+        return "unclassified"
     except Exception:
         return "unclassified"
     finally:
