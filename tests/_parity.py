@@ -2207,6 +2207,24 @@ def mpsa_whole_grid_check(lib, n: int = 16):
     out["u_norm_rel_diff"] = float(abs(np.linalg.norm(u) - z["u_norm"][0]) / z["u_norm"][0])
     ud, ur = bench.vector_digest(u, blocks), z["u_digest"]
     out["u_block_squares_worst_rel_diff"] = float(np.max(np.abs(ud[1] - ur[1]) / np.maximum(ur[1], 1e-300)))
+    # the fine datum (oracle/gen_golden_mpsa_fine.py): per block of 256 rows sum |a| and max |a| of the reference's matrices
+    fine = os.path.join(os.path.dirname(__file__), "golden", f"mpsawhole_fine_{n}.npz")
+    if os.path.exists(fine):
+        zf = np.load(fine)
+        assert json.loads(str(zf["info"]))["cells"] == g.num_cells
+        worst_sum = worst_max = 0.0
+        blocks_checked = 0
+        for k in MPSA_KEYS:
+            mask = mpsa_stress_rows_that_count(pa.grid_to_raw(g), is_neu) if k == "stress" else None
+            dev, ref = bench.fine_digest(mats[k], rows_mask=mask), zf[k + "_fine"]
+            assert dev.shape == ref.shape, (k, dev.shape, ref.shape)
+            nz = ref[0] > 0.0
+            assert np.all(dev[0][~nz] <= 1e-13 * np.max(ref[0])), k  # (blocks the reference leaves empty stay empty)
+            worst_sum = max(worst_sum, float(np.max(np.abs(dev[0][nz] - ref[0][nz]) / ref[0][nz])))
+            worst_max = max(worst_max, float(np.max(np.abs(dev[1][nz] - ref[1][nz]) / ref[1][nz])))
+            blocks_checked += int(nz.sum())
+        out["fine"] = {"blocks_of_256_rows": blocks_checked, "worst_rel_diff_of_block_sums": worst_sum,
+                       "worst_rel_diff_of_block_maxima": worst_max}
     return out
 
 
