@@ -187,6 +187,10 @@ def test_all_four_matrices_and_the_displacement_field_on_a_whole_grid_against_th
     for k in P.MPSA_KEYS:
         assert max(out[k]) < 1e-12, (k, out[k])
     assert out["u_norm_rel_diff"] < 1e-10 and out["u_block_squares_worst_rel_diff"] < 1e-9, out
+    # ... and the fine datum (oracle/gen_golden_mpsa_fine.py): sum |a| and max |a| of every block of 256 rows of the
+    # reference's four matrices (observed: 1.9e-15 / 4.5e-15 over 928 blocks)
+    assert out["fine"]["blocks_of_256_rows"] > 900
+    assert out["fine"]["worst_rel_diff_of_block_sums"] < 1e-13 and out["fine"]["worst_rel_diff_of_block_maxima"] < 1e-12, out["fine"]
 
 
 def test_biot_coupling_terms_on_a_whole_grid_against_the_reference(lib):
