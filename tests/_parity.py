@@ -671,6 +671,55 @@ def amg_filter_layout_states(lib, n=6):
     return states
 
 
+def amg_fused_cycle_is_the_same_operator(lib, g, env=None, rtol=1e-12):
+    """The fused forms of the cycle's larger coarse levels (PFV_AMG_FUSE_CYCLE, amg.inc: amg_cycle -- the prolongation inside
+    the post-smoothing product, the second visit's residual + first smoothing step in one product, its correction folded
+    into the parent's prolongation) apply the SAME linear operator as the launches they replace: same iteration count, the
+    same solution to rounding, fewer launches.  ``env``: extra switches that bring the fused forms into play on a small
+    grid (PFV_AMG_FUSE_ROWS=0: no level takes the small-level launches; PFV_AMG_GAMMA=2: first coarse level visited twice)."""
+    rng = np.random.default_rng(4)
+    nc = g.num_cells
+    sc = np.exp(0.5 * rng.standard_normal(nc))
+    kw = dict(kxx=sc, kyy=3 * sc, kxy=0.3 * sc)
+    if g.dim == 3:
+        kw.update(kzz=0.4 * sc, kyz=0.1 * sc)
+    bf = g.get_all_boundary_faces()
+    xf = g.face_centers[0, bf]
+    dirf = bf[(xf < 1e-9) | (xf > g.nodes[0].max() - 1e-9)]
+    bv = np.zeros(g.num_faces)
+    bv[dirf] = g.face_centers[0, dirf]
+    keys = dict(env or {})
+    keys.setdefault("PFV_AMG_FUSE_CYCLE", "1")
+    saved = {k: os.environ.get(k) for k in keys}
+    res = {}
+    try:
+        for fused in ("0", "1"):
+            for k, v in keys.items():
+                os.environ[k] = v
+            os.environ["PFV_AMG_FUSE_CYCLE"] = fused
+            data = pa.initialize_data({}, "flow", {"second_order_tensor": pa.SecondOrderTensor(**kw),
+                                                   "bc": pa.BoundaryCondition(g, dirf, ["dir"] * dirf.size), "bc_values": bv})
+            d = pa.Mpfa("flow", library=lib)
+            d.discretize(g, data)
+            d.assemble_matrix_rhs(g, data)
+            x, info = d.solve(g, data, source=g.cell_volumes, method="bicgstab", rtol=rtol, precond="amg")
+            assert info["converged"], (fused, info)
+            st = d.context(g).stats()
+            res[fused] = (x, info["iterations"], int(st.get("solve_launches", 0)), int(st["amg_levels"]))
+            d.context(g).close()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    (x0, it0, l0, lev), (x1, it1, l1, _) = res["0"], res["1"]
+    assert lev >= 3, lev  # (a coarse level with a level below it: something to fuse)
+    assert abs(it1 - it0) <= 1, (it0, it1)
+    assert np.linalg.norm(x1 - x0) <= 1e-9 * np.linalg.norm(x0)
+    return {"iterations": (it0, it1), "launches": (l0, l1), "levels": lev}
+
+
 def amg_preconditioner(lib, g, seed=2, hetero_sigma=0.5):
     """Aggregation-AMG-preconditioned solves against the direct solution of the same system, far fewer
     iterations than Jacobi, bitwise repeatable."""

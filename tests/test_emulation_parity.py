@@ -226,6 +226,18 @@ def test_amg_filter_keeps_its_row_layout_only_after_a_setup_that_reproduced_it(l
     P.amg_filter_layout_states(lib)
 
 
+@pytest.mark.parametrize("env", [{"PFV_AMG_FUSE_ROWS": "0", "PFV_AMG_GAMMA": "2"},
+                                 {"PFV_AMG_FUSE_ROWS": "0", "PFV_AMG_GAMMA": "1"},
+                                 {"PFV_AMG_FUSE_ROWS": "0", "PFV_AMG_GAMMA": "2", "PFV_AMG_GAMMA_LEVELS": "2"},
+                                 {"PFV_AMG_FUSE_ROWS": "1000", "PFV_AMG_GAMMA": "2", "PFV_AMG_GAMMA_LEVELS": "2"}])
+def test_amg_fused_cycle_is_the_same_operator(lib, env):
+    g = pa.StructuredTetrahedralGrid([18, 18, 18], [1, 1, 1])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.015)
+    out = P.amg_fused_cycle_is_the_same_operator(lib, g, env=env)
+    assert out["levels"] >= 4 and out["iterations"][0] == out["iterations"][1], out
+
+
 def test_amg_preconditioner(lib):
     g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([10, 10, 10], [1, 1, 1])), 0.02)
     out, jac, st = P.amg_preconditioner(lib, g)

@@ -216,6 +216,24 @@ def test_amg_filter_keeps_its_row_layout_only_after_a_setup_that_reproduced_it(l
     P.amg_filter_layout_states(lib)
 
 
+@pytest.mark.parametrize("env", [{}, {"PFV_AMG_GAMMA": "2"}, {"PFV_AMG_GAMMA": "2", "PFV_AMG_GAMMA_LEVELS": "2"},
+                                 {"PFV_AMG_FUSE_ROWS": "0", "PFV_AMG_GAMMA": "2"}])
+def test_amg_fused_cycle_is_the_same_operator(lib, env):
+    """The windowed forms (k_spmv_win MODE 4 / 5) on a grid whose first coarse level has an SpMV window: same iterations,
+    same solution, fewer launches than the launches they replace (PFV_AMG_FUSE_CYCLE=0)."""
+    g = pa.StructuredTetrahedralGrid([24, 24, 24], [1, 1, 1])
+    g.compute_geometry()
+    g = pa.perturb_interior_nodes(g, 0.012)
+    out = P.amg_fused_cycle_is_the_same_operator(lib, g, env=env)
+    print("fused cycle:", env, out)
+    assert abs(out["iterations"][0] - out["iterations"][1]) <= 1, out
+    # (default switches at this size: a V-cycle whose coarse levels all take the small-level launches -- nothing to fuse)
+    per_it = [out["launches"][k] / out["iterations"][k] for k in (0, 1)]
+    assert per_it[1] <= per_it[0], out
+    if env.get("PFV_AMG_FUSE_ROWS") == "0":
+        assert per_it[1] < per_it[0] - 3, out
+
+
 def test_amg_preconditioner(lib):
     g = pa.perturb_interior_nodes(_geo(pa.StructuredTetrahedralGrid([12, 12, 12], [1, 1, 1])), 0.015)
     P.amg_preconditioner(lib, g)
