@@ -5,7 +5,7 @@ its FOUR matrices, per block of 256 consecutive rows: sum |a| and max |a| (``ben
 belong to Neumann components of boundary faces left out as in the first datum -- their true entries are all zero).
 -> tests/golden/mpsawhole_fine_<n>.npz
 
-TEST INFRASTRUCTURE; build container only (n = 12: 1 min; n = 20: 5 min; n = 32 with 6 sub-problems: 22 min):
+TEST INFRASTRUCTURE; build container only (n = 12: 1 min; n = 20: 3 min; n = 32 with 6 sub-problems: 16 min; n = 44 with 16: 51 min):
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/repo/oracle/shim:/root/reference/src:/root/repo \
       python /root/repo/oracle/gen_golden_mpsa_fine.py [n_side = 12] [num_subproblems = 1]
 """
